@@ -1,0 +1,744 @@
+/*
+ * fastrank_oracle.c -- CPU restatement of the jjfiv/fastrank coordinate-ascent hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *checker* for the HIP product path in
+ * fastrank_amd/csrc/.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product library (libfastrank_amd.so) never links, dlopens or
+ * calls anything in oracle/.
+ *
+ * Parity status
+ * -------------
+ *   * evaluator semantics (score, 3-key order, NDCG[@k], AP, RR, mean): PINNED by the
+ *     reference's own known answers (tests/test_oracle_golden.py):
+ *       - src/evaluators.rs:61-79   tie order  [4,3,1,2,5]
+ *       - src/evaluators.rs:285-295 NDCG([0,1,1,1,0,0]) = 0.7328 +- 5e-5
+ *       - tests/test_with_example_data.py:16-23  six single-feature mean NDCG@5 values
+ *       - src/random_forest.rs:465-506 tree scoring rule (fval <= split -> lhs)
+ *   * seed -> trajectory (Rand64 = third-party crate oorandom =11.1.0, absent from
+ *     /root/reference): PARITY UNPINNED.  oracle_rand64_* restates oorandom's published
+ *     PCG algorithm from memory; nothing in the reference tree pins its output except an
+ *     RNG-dependent random-forest known answer that needs RF *training* (out of scope).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/).  The reference cannot be compiled here (no cargo/rustc), so there
+ * is no oracle/_ref build.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------ */
+/* Rand64: oorandom =11.1.0 (Cargo.toml:18-19).  PARITY UNPINNED (see header).           */
+/* ------------------------------------------------------------------------------------ */
+
+typedef unsigned __int128 u128;
+
+typedef struct {
+    u128 state;
+    u128 inc;
+} oracle_rand64;
+
+static const u128 RAND64_MULT =
+    (((u128)2549297995355413924ULL) << 64) | (u128)4865540595714422341ULL; /* 47026247687942121848144207491837523525 */
+static const u128 RAND64_DEFAULT_INC =
+    (((u128)0x2FE0E169FFBD06E3ULL) << 64) | (u128)0x5BC307BD4D2F814FULL;
+
+uint64_t oracle_rand64_u64(oracle_rand64 *r) {
+    u128 old = r->state;
+    r->state = old * RAND64_MULT + r->inc;
+    uint64_t xorshifted = (uint64_t)(((old >> 29) ^ old) >> 58);
+    uint32_t rot = (uint32_t)(old >> 122);
+    return (xorshifted >> rot) | (xorshifted << ((64 - rot) & 63));
+}
+
+/* Rand64::new(seed): used at src/coordinate_ascent.rs:27,199,212 */
+void oracle_rand64_new(oracle_rand64 *r, uint64_t seed) {
+    r->state = 0;
+    r->inc = (RAND64_DEFAULT_INC << 1) | 1;
+    (void)oracle_rand64_u64(r);
+    r->state += (u128)seed;
+    (void)oracle_rand64_u64(r);
+}
+
+/* rand_float(): [0,1) with 54 bits, used at src/coordinate_ascent.rs:53 */
+double oracle_rand64_float(oracle_rand64 *r) {
+    uint64_t u = oracle_rand64_u64(r);
+    u >>= (64 - 54);
+    return (double)u * (1.0 / 18014398509481984.0); /* 2^-54 */
+}
+
+/* rand_range(lo..hi): Lemire multiply-shift with rejection, used at src/randutil.rs:24 */
+uint64_t oracle_rand64_range(oracle_rand64 *r, uint64_t lo, uint64_t hi) {
+    uint64_t s = hi - lo;
+    u128 m = (u128)oracle_rand64_u64(r) * (u128)s;
+    uint64_t leftover = (uint64_t)m;
+    if (leftover < s) {
+        uint64_t threshold = (0 - s) % s;
+        while (leftover < threshold) {
+            m = (u128)oracle_rand64_u64(r) * (u128)s;
+            leftover = (uint64_t)m;
+        }
+    }
+    return (uint64_t)(m >> 64) + lo;
+}
+
+/* src/randutil.rs:21-27: forward Fisher-Yates */
+static void shuffle_u32(uint32_t *v, size_t n, oracle_rand64 *r) {
+    for (size_t i = 0; i < n; i++) {
+        size_t j = (size_t)oracle_rand64_range(r, i, n);
+        uint32_t t = v[i];
+        v[i] = v[j];
+        v[j] = t;
+    }
+}
+
+/* Test hooks for the RNG (python cannot hold a u128 struct by value comfortably). */
+void oracle_rand64_stream(uint64_t seed, size_t n, uint64_t *out) {
+    oracle_rand64 r;
+    oracle_rand64_new(&r, seed);
+    for (size_t i = 0; i < n; i++) out[i] = oracle_rand64_u64(&r);
+}
+void oracle_shuffle_with_seed(uint64_t seed, uint32_t *v, size_t n) {
+    oracle_rand64 r;
+    oracle_rand64_new(&r, seed);
+    shuffle_u32(v, n, &r);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Dataset: DenseDataset (src/dense_dataset.rs:11-56) -- borrowed row-major f32 matrix.  */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    size_t n, d;
+    const float *x;   /* row-major n x d, borrowed (src/lib.rs:224-240) */
+    const double *y;  /* labels, borrowed */
+    size_t nq;
+    uint32_t *qid;    /* [nq] query ids in first-appearance order */
+    size_t *qoff;     /* [nq+1] */
+    uint32_t *qdocs;  /* [n] instance ids grouped by query, ascending inside a query
+                         (src/dense_dataset.rs:96-109) */
+} oracle_dataset;
+
+typedef struct {
+    uint32_t qid;
+    uint32_t idx;
+} qpair;
+static int cmp_qpair(const void *a, const void *b) {
+    const qpair *x = (const qpair *)a, *y = (const qpair *)b;
+    if (x->qid != y->qid) return x->qid < y->qid ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+/* src/dense_dataset.rs:28-55: every qid must fit u32 (u32::try_from(i64)). Returns NULL on
+ * out-of-range qid. Query order here = order of first appearance (the reference's order is
+ * a fresh HashMap's, i.e. unspecified: SURVEY.md A.2). */
+oracle_dataset *oracle_dataset_new(size_t n, size_t d, const float *x, const double *y,
+                                   const int64_t *qids) {
+    for (size_t i = 0; i < n; i++)
+        if (qids[i] < 0 || qids[i] > (int64_t)UINT32_MAX) return NULL;
+    oracle_dataset *ds = (oracle_dataset *)calloc(1, sizeof(*ds));
+    ds->n = n;
+    ds->d = d;
+    ds->x = x;
+    ds->y = y;
+    qpair *p = (qpair *)malloc(sizeof(qpair) * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) {
+        p[i].qid = (uint32_t)qids[i];
+        p[i].idx = (uint32_t)i;
+    }
+    qsort(p, n, sizeof(qpair), cmp_qpair);
+    /* groups sorted by qid; now order groups by first appearance (= min idx = first elem) */
+    size_t nq = 0;
+    for (size_t i = 0; i < n; i++)
+        if (i == 0 || p[i].qid != p[i - 1].qid) nq++;
+    qpair *heads = (qpair *)malloc(sizeof(qpair) * (nq ? nq : 1)); /* (first idx, start) */
+    size_t *glen = (size_t *)malloc(sizeof(size_t) * (nq ? nq : 1));
+    size_t g = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (i == 0 || p[i].qid != p[i - 1].qid) {
+            heads[g].qid = p[i].idx;      /* first appearance */
+            heads[g].idx = (uint32_t)i;   /* start in p */
+            glen[g] = 0;
+            g++;
+        }
+        glen[g - 1]++;
+    }
+    /* sort groups by first appearance; keep glen aligned through an index sort */
+    size_t *order = (size_t *)malloc(sizeof(size_t) * (nq ? nq : 1));
+    for (size_t i = 0; i < nq; i++) order[i] = i;
+    /* simple insertion-free approach: qsort on heads copy with index in .idx is lossy, so
+       sort an array of (first, groupindex) */
+    qpair *ho = (qpair *)malloc(sizeof(qpair) * (nq ? nq : 1));
+    for (size_t i = 0; i < nq; i++) {
+        ho[i].qid = heads[i].qid;
+        ho[i].idx = (uint32_t)i;
+    }
+    qsort(ho, nq, sizeof(qpair), cmp_qpair);
+    ds->nq = nq;
+    ds->qid = (uint32_t *)malloc(sizeof(uint32_t) * (nq ? nq : 1));
+    ds->qoff = (size_t *)malloc(sizeof(size_t) * (nq + 1));
+    ds->qdocs = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    size_t w = 0;
+    for (size_t k = 0; k < nq; k++) {
+        size_t gi = ho[k].idx;
+        size_t start = heads[gi].idx;
+        ds->qid[k] = p[start].qid;
+        ds->qoff[k] = w;
+        for (size_t t = 0; t < glen[gi]; t++) ds->qdocs[w++] = p[start + t].idx;
+    }
+    ds->qoff[nq] = w;
+    free(order);
+    free(ho);
+    free(glen);
+    free(heads);
+    free(p);
+    return ds;
+}
+
+void oracle_dataset_free(oracle_dataset *ds) {
+    if (!ds) return;
+    free(ds->qid);
+    free(ds->qoff);
+    free(ds->qdocs);
+    free(ds);
+}
+
+size_t oracle_num_queries(const oracle_dataset *ds) { return ds->nq; }
+void oracle_query_ids(const oracle_dataset *ds, uint32_t *out) {
+    memcpy(out, ds->qid, sizeof(uint32_t) * ds->nq);
+}
+void oracle_query_offsets(const oracle_dataset *ds, uint64_t *out) {
+    for (size_t i = 0; i <= ds->nq; i++) out[i] = (uint64_t)ds->qoff[i];
+}
+void oracle_query_docs(const oracle_dataset *ds, uint32_t *out) {
+    memcpy(out, ds->qdocs, sizeof(uint32_t) * ds->n);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Scoring                                                                               */
+/* ------------------------------------------------------------------------------------ */
+
+/* src/dense_dataset.rs:67-76 + src/model.rs:47-51: out = 0.0; out += f64(x_j) * w_j, j
+ * ascending, multiply then add (this TU is built with -ffp-contract=off).  zip() stops at
+ * the shorter of (row, weights).  */
+static inline double dotp(const float *row, size_t d, const double *w, size_t wlen) {
+    size_t m = d < wlen ? d : wlen;
+    double out = 0.0;
+    for (size_t j = 0; j < m; j++) {
+        double prod = (double)row[j] * w[j];
+        out = out + prod;
+    }
+    return out;
+}
+
+void oracle_score_linear(const oracle_dataset *ds, const double *w, size_t wlen, double *out) {
+    for (size_t i = 0; i < ds->n; i++) out[i] = dotp(ds->x + i * ds->d, ds->d, w, wlen);
+}
+
+/* Flattened tree ensemble (src/model.rs:53-112).  node arrays are concatenated over trees;
+ * tree t's root is node root[t].  A node with fid < 0 is a leaf whose value is `split`.
+ * Internal: go lhs when f64(x[fid]) <= split else rhs (src/model.rs:75-79).  Missing /
+ * out-of-range features read 0.0 for loaded datasets (unwrap_or(0.0)); DenseDataset panics
+ * (dense_dataset.rs:145) -- the caller must validate.  Ensemble:
+ * out = 0; out += weight_t * score_t in order (src/model.rs:104-112). */
+void oracle_score_ensemble(const oracle_dataset *ds, size_t ntrees, const int32_t *root,
+                           const double *tweight, const int32_t *fid, const double *split,
+                           const int32_t *lhs, const int32_t *rhs, double *out) {
+    for (size_t i = 0; i < ds->n; i++) {
+        const float *row = ds->x + i * ds->d;
+        double acc = 0.0;
+        for (size_t t = 0; t < ntrees; t++) {
+            int32_t node = root[t];
+            while (fid[node] >= 0) {
+                double v = ((size_t)fid[node] < ds->d) ? (double)row[fid[node]] : 0.0;
+                node = (v <= split[node]) ? lhs[node] : rhs[node];
+            }
+            double prod = tweight[t] * split[node];
+            acc = acc + prod;
+        }
+        out[i] = acc;
+    }
+}
+
+/* src/model.rs:35-40 SingleFeatureModel: dir * val */
+void oracle_score_single_feature(const oracle_dataset *ds, uint32_t fid, double dir, double *out) {
+    for (size_t i = 0; i < ds->n; i++) {
+        double v = (fid < ds->d) ? (double)ds->x[i * ds->d + fid] : 0.0;
+        out[i] = dir * v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Ranking order and metrics                                                             */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    double score;
+    float gain;
+    uint32_t id;
+} ranked;
+
+/* src/evaluators.rs:34-49: score desc, gain asc, id asc; NotNan cmp => -0.0 == +0.0 */
+static int cmp_ranked(const void *a, const void *b) {
+    const ranked *x = (const ranked *)a, *y = (const ranked *)b;
+    if (x->score > y->score) return -1;
+    if (x->score < y->score) return 1;
+    if (x->gain < y->gain) return -1;
+    if (x->gain > y->gain) return 1;
+    if (x->id < y->id) return -1;
+    if (x->id > y->id) return 1;
+    return 0;
+}
+
+/* exposed for the comparator known-answer test (src/evaluators.rs:61-79) */
+void oracle_rank_order(size_t n, const double *score, const float *gain, const uint32_t *id,
+                       uint32_t *out_ids) {
+    ranked *r = (ranked *)malloc(sizeof(ranked) * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) {
+        r[i].score = score[i];
+        r[i].gain = gain[i];
+        r[i].id = id[i];
+    }
+    qsort(r, n, sizeof(ranked), cmp_ranked);
+    for (size_t i = 0; i < n; i++) out_ids[i] = r[i].id;
+    free(r);
+}
+
+static int cmp_f32_desc(const void *a, const void *b) {
+    float x = *(const float *)a, y = *(const float *)b;
+    return x > y ? -1 : (x < y);
+}
+
+/* src/evaluators.rs:255-272 compute_dcg: optional descending sort (ideal), truncate or
+ * zero-pad to depth, then sum_i (2^g_i - 1) / log2(i + 2), sequential, i from 0.
+ * depth < 0 means None. */
+double oracle_compute_dcg(const float *gains, size_t n, int64_t depth, int ideal) {
+    size_t len = depth >= 0 ? (size_t)depth : n;
+    float *g = (float *)calloc(len ? len : 1, sizeof(float));
+    if (ideal) {
+        float *tmp = (float *)malloc(sizeof(float) * (n ? n : 1));
+        memcpy(tmp, gains, sizeof(float) * n);
+        qsort(tmp, n, sizeof(float), cmp_f32_desc);
+        memcpy(g, tmp, sizeof(float) * (n < len ? n : len));
+        free(tmp);
+    } else {
+        memcpy(g, gains, sizeof(float) * (n < len ? n : len));
+    }
+    double dcg = 0.0;
+    for (size_t i = 0; i < len; i++) {
+        double gain = (double)g[i];
+        double term = (pow(2.0, gain) - 1.0) / log2((double)i + 2.0);
+        dcg = dcg + term;
+    }
+    free(g);
+    return dcg;
+}
+
+/* src/evaluators.rs:303-340 NDCG::new norm for one gain list: NaN encodes None (no gain > 0) */
+double oracle_ideal_dcg(const float *gains, size_t n, int64_t depth) {
+    size_t pos = 0;
+    for (size_t i = 0; i < n; i++)
+        if (gains[i] > 0.0f) pos++;
+    if (pos == 0) return NAN;
+    return oracle_compute_dcg(gains, n, depth, 1);
+}
+
+enum { ORACLE_NDCG = 0, ORACLE_AP = 1, ORACLE_RR = 2 };
+
+/* Default norms from the dataset itself (judgments == None):
+ *   NDCG: ideal DCG of the query's own gains (evaluators.rs:319-333), NaN = None
+ *   AP:   number of docs with gain > 0      (evaluators.rs:403-408), 0 = absent
+ *   RR:   unused */
+void oracle_default_norms(const oracle_dataset *ds, int measure, int64_t depth, double *out) {
+    for (size_t q = 0; q < ds->nq; q++) {
+        size_t a = ds->qoff[q], b = ds->qoff[q + 1];
+        if (measure == ORACLE_NDCG) {
+            float *g = (float *)malloc(sizeof(float) * (b - a ? b - a : 1));
+            for (size_t k = a; k < b; k++) g[k - a] = (float)ds->y[ds->qdocs[k]];
+            out[q] = oracle_ideal_dcg(g, b - a, depth);
+            free(g);
+        } else if (measure == ORACLE_AP) {
+            size_t c = 0;
+            for (size_t k = a; k < b; k++)
+                if ((float)ds->y[ds->qdocs[k]] > 0.0f) c++;
+            out[q] = (double)c;
+        } else {
+            out[q] = 0.0;
+        }
+    }
+}
+
+/* One query's metric from its sorted ranked list.  Returns NaN-free value; *err set when the
+ * reference would panic (NDCG actual > ideal, evaluators.rs:368-374). */
+static double metric_of_ranked(const ranked *r, size_t n, int measure, int64_t depth,
+                               double norm, int *err) {
+    if (measure == ORACLE_NDCG) {
+        /* evaluators.rs:350-380 */
+        if (isnan(norm)) return 0.0;
+        size_t len = depth >= 0 ? (size_t)depth : n;
+        double dcg = 0.0;
+        for (size_t i = 0; i < len; i++) {
+            double gain = i < n ? (double)r[i].gain : 0.0;
+            double term = (pow(2.0, gain) - 1.0) / log2((double)i + 2.0);
+            dcg = dcg + term;
+        }
+        if (dcg > norm) {
+            if (err) *err = 1;
+        }
+        return dcg / norm;
+    } else if (measure == ORACLE_AP) {
+        /* evaluators.rs:422-447; norm = num_relevant (0 => fall back to the list's count) */
+        uint32_t num_rel = (uint32_t)norm;
+        if (num_rel == 0) {
+            for (size_t i = 0; i < n; i++)
+                if (r[i].gain > 0.0f) num_rel++;
+        }
+        if (num_rel == 0) return 0.0;
+        int32_t recall_points = 0;
+        double sum_precision = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            if (r[i].gain > 0.0f) {
+                recall_points += 1;
+                sum_precision += (double)recall_points / (double)(i + 1);
+            }
+        }
+        return sum_precision / (double)num_rel;
+    } else {
+        /* evaluators.rs:239-252 */
+        for (size_t i = 0; i < n; i++)
+            if (r[i].gain > 0.0f) return 1.0 / (double)(i + 1);
+        return 0.0;
+    }
+}
+
+/* src/evaluators.rs:206-224 evaluate_to_vec given precomputed per-instance scores (indexed by
+ * original instance id).  out[q] in this dataset's query order.  Also optionally returns the
+ * full rank order (instance ids, grouped by query in qoff layout) for rank-parity tests.
+ * Returns nonzero if the reference would have panicked. */
+int oracle_metric_from_scores(const oracle_dataset *ds, int measure, int64_t depth,
+                              const double *scores, const double *norms, double *out,
+                              uint32_t *out_rank_ids) {
+    int err = 0;
+    size_t maxlen = 0;
+    for (size_t q = 0; q < ds->nq; q++) {
+        size_t l = ds->qoff[q + 1] - ds->qoff[q];
+        if (l > maxlen) maxlen = l;
+    }
+    ranked *r = (ranked *)malloc(sizeof(ranked) * (maxlen ? maxlen : 1));
+    for (size_t q = 0; q < ds->nq; q++) {
+        size_t a = ds->qoff[q], b = ds->qoff[q + 1];
+        for (size_t k = a; k < b; k++) {
+            uint32_t id = ds->qdocs[k];
+            r[k - a].score = scores[id];
+            r[k - a].gain = (float)ds->y[id]; /* dense_dataset.rs:114-123 */
+            r[k - a].id = id;
+            if (isnan(scores[id])) err |= 2; /* model.rs:49 would panic */
+        }
+        qsort(r, b - a, sizeof(ranked), cmp_ranked);
+        if (out_rank_ids)
+            for (size_t k = a; k < b; k++) out_rank_ids[k] = r[k - a].id;
+        out[q] = metric_of_ranked(r, b - a, measure, depth, norms[q], &err);
+    }
+    free(r);
+    return err;
+}
+
+/* src/evaluators.rs:173-184: mean over all queries, sequential sum in this dataset's query
+ * order; 0.0 when there are no queries. */
+static double mean_seq(const double *v, size_t n) {
+    if (n == 0) return 0.0;
+    double sum = 0.0;
+    for (size_t i = 0; i < n; i++) sum += v[i];
+    return sum / (double)n;
+}
+
+typedef struct {
+    double *scores; /* [n] */
+    double *perq;   /* [nq] */
+    ranked *r;      /* [maxlen] */
+    size_t maxlen;
+} eval_ws;
+
+static void ws_init(eval_ws *ws, const oracle_dataset *ds) {
+    size_t maxlen = 0;
+    for (size_t q = 0; q < ds->nq; q++) {
+        size_t l = ds->qoff[q + 1] - ds->qoff[q];
+        if (l > maxlen) maxlen = l;
+    }
+    ws->maxlen = maxlen;
+    ws->scores = (double *)malloc(sizeof(double) * (ds->n ? ds->n : 1));
+    ws->perq = (double *)malloc(sizeof(double) * (ds->nq ? ds->nq : 1));
+    ws->r = (ranked *)malloc(sizeof(ranked) * (maxlen ? maxlen : 1));
+}
+static void ws_free(eval_ws *ws) {
+    free(ws->scores);
+    free(ws->perq);
+    free(ws->r);
+}
+
+/* evaluate_mean for a linear model with a reusable workspace (the hoisted-HashMap deviation
+ * stated in BASELINE.md section 3: grouping is done once, not per call). */
+static double evaluate_mean_linear_ws(const oracle_dataset *ds, int measure, int64_t depth,
+                                      const double *norms, const double *w, size_t wlen,
+                                      eval_ws *ws, int *err) {
+    for (size_t q = 0; q < ds->nq; q++) {
+        size_t a = ds->qoff[q], b = ds->qoff[q + 1];
+        for (size_t k = a; k < b; k++) {
+            uint32_t id = ds->qdocs[k];
+            ws->r[k - a].score = dotp(ds->x + (size_t)id * ds->d, ds->d, w, wlen);
+            ws->r[k - a].gain = (float)ds->y[id];
+            ws->r[k - a].id = id;
+            if (isnan(ws->r[k - a].score)) *err |= 2;
+        }
+        qsort(ws->r, b - a, sizeof(ranked), cmp_ranked);
+        ws->perq[q] = metric_of_ranked(ws->r, b - a, measure, depth, norms[q], err);
+    }
+    return mean_seq(ws->perq, ds->nq);
+}
+
+double oracle_evaluate_mean_linear(const oracle_dataset *ds, int measure, int64_t depth,
+                                   const double *norms, const double *w, size_t wlen) {
+    eval_ws ws;
+    int err = 0;
+    ws_init(&ws, ds);
+    double m = evaluate_mean_linear_ws(ds, measure, depth, norms, w, wlen, &ws, &err);
+    ws_free(&ws);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Coordinate ascent (src/coordinate_ascent.rs:43-254)                                   */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    uint32_t num_restarts;
+    uint32_t num_max_iterations;
+    double step_base;
+    double step_scale;
+    double tolerance;
+    uint64_t seed;
+    int32_t normalize;
+    int32_t init_random;
+    /* bounded-sample hook for bench.py's cpu_baseline: stop a restart after this many
+     * evaluate_mean calls (0 = unlimited = reference behaviour) */
+    uint64_t max_evals_per_restart;
+} oracle_ca_params;
+
+/* coordinate_ascent.rs:72-82 */
+static void l1_normalize(double *w, size_t n) {
+    double sum = 0.0;
+    for (size_t i = 0; i < n; i++) sum += fabs(w[i]);
+    if (sum > 0.0)
+        for (size_t i = 0; i < n; i++) w[i] /= sum;
+}
+
+typedef struct {
+    const oracle_dataset *ds;
+    const oracle_ca_params *p;
+    int measure;
+    int64_t depth;
+    const double *norms;
+    const uint32_t *fids;
+    size_t nf;
+    size_t dim;
+    uint64_t child_seed;
+    double *out_w;      /* [dim] */
+    double out_score;
+    uint64_t n_evals;
+    int err;
+} restart_job;
+
+/* coordinate_ascent.rs:87-195 optimize_inner */
+static void optimize_inner(restart_job *job) {
+    const oracle_ca_params *p = job->p;
+    size_t dim = job->dim, nf = job->nf;
+    oracle_rand64 rand;
+    oracle_rand64_new(&rand, job->child_seed);
+    eval_ws ws;
+    ws_init(&ws, job->ds);
+    double *model = (double *)calloc(dim, sizeof(double));
+    double *best = (double *)calloc(dim, sizeof(double));
+    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * nf);
+    uint64_t evals = 0;
+    int stop = 0;
+
+    /* reset(): coordinate_ascent.rs:50-70 */
+    if (p->init_random) {
+        for (size_t k = 0; k < nf; k++) model[job->fids[k]] = oracle_rand64_float(&rand) * 2.0 - 1.0;
+    } else {
+        for (size_t k = 0; k < nf; k++) model[job->fids[k]] = 1.0 / (double)nf;
+    }
+    double best_score = evaluate_mean_linear_ws(job->ds, job->measure, job->depth, job->norms,
+                                                model, dim, &ws, &job->err);
+    evals++;
+    memcpy(best, model, sizeof(double) * dim);
+
+    while (!stop) {
+        memcpy(order, job->fids, sizeof(uint32_t) * nf);
+        shuffle_u32(order, nf, &rand);
+        size_t successes = 0;
+        for (size_t k = 0; k < nf && !stop; k++) {
+            uint32_t f = order[k];
+            double start_score = best_score;
+            memcpy(model, best, sizeof(double) * dim);
+            if (p->normalize) l1_normalize(model, dim);
+            double orig = model[f];
+            static const int SIGN[3] = {0, -1, 1}; /* coordinate_ascent.rs:85 */
+            for (int s = 0; s < 3 && !stop; s++) {
+                double dir = (double)SIGN[s];
+                double step = p->step_base * dir;
+                if (orig != 0.0 && fabs(step) > 0.5 * fabs(orig)) step = p->step_base * fabs(orig) * dir;
+                double total = step;
+                uint32_t iters = p->num_max_iterations;
+                if (SIGN[s] == 0) {
+                    iters = 1;
+                    total = -orig;
+                }
+                for (uint32_t it = 0; it < iters; it++) {
+                    double w = orig + total;
+                    model[f] = w;
+                    double sc = evaluate_mean_linear_ws(job->ds, job->measure, job->depth,
+                                                        job->norms, model, dim, &ws, &job->err);
+                    evals++;
+                    /* core.rs:57-66 replace_if_better: NaN rejected, strict > */
+                    if (!isnan(sc) && sc > best_score) {
+                        best_score = sc;
+                        memcpy(best, model, sizeof(double) * dim);
+                    }
+                    step *= p->step_scale;
+                    total += step;
+                    if (p->max_evals_per_restart && evals >= p->max_evals_per_restart) {
+                        stop = 1;
+                        break;
+                    }
+                }
+                if (best_score - start_score > p->tolerance) break;
+            }
+            if (best_score - start_score > p->tolerance) successes++;
+        }
+        if (successes == 0) break;
+    }
+    memcpy(job->out_w, best, sizeof(double) * dim);
+    job->out_score = best_score;
+    job->n_evals = evals;
+    free(order);
+    free(best);
+    free(model);
+    ws_free(&ws);
+}
+
+typedef struct {
+    restart_job *jobs;
+    size_t njobs;
+    size_t next;
+    pthread_mutex_t mu;
+} job_queue;
+
+static void *worker(void *arg) {
+    job_queue *q = (job_queue *)arg;
+    for (;;) {
+        pthread_mutex_lock(&q->mu);
+        size_t i = q->next++;
+        pthread_mutex_unlock(&q->mu);
+        if (i >= q->njobs) break;
+        optimize_inner(&q->jobs[i]);
+    }
+    return NULL;
+}
+
+/* coordinate_ascent.rs:198-253 learn(): child seeds drawn in restart order from the master
+ * RNG; restarts run on `threads` workers (rayon's restart-only parallelism, :216); returns
+ * every restart's (score, weights[dim]) so the caller can apply either selection rule
+ * (:232-251).  fids = data.features() (ascending for DenseDataset); dim = max(fid)+1.
+ * restart_begin/end select a shard of restarts [begin,end) (all child seeds are still drawn
+ * in order from the master).  Returns nonzero if the reference would have panicked. */
+int oracle_ca_learn(const oracle_dataset *ds, const oracle_ca_params *p, int measure,
+                    int64_t depth, const double *norms, const uint32_t *fids, size_t nf,
+                    size_t threads, uint32_t restart_begin, uint32_t restart_end,
+                    double *out_scores /*[R]*/, double *out_weights /*[R*dim]*/,
+                    uint64_t *out_evals /*[R]*/) {
+    if (nf == 0 || ds->n == 0 || ds->nq == 0) return 4; /* :201-203 asserts */
+    size_t dim = 0;
+    for (size_t k = 0; k < nf; k++)
+        if ((size_t)fids[k] + 1 > dim) dim = (size_t)fids[k] + 1;
+    uint32_t R = p->num_restarts;
+    if (restart_end > R) restart_end = R;
+    oracle_rand64 master;
+    oracle_rand64_new(&master, p->seed);
+    uint64_t *child = (uint64_t *)malloc(sizeof(uint64_t) * (R ? R : 1));
+    for (uint32_t r = 0; r < R; r++) child[r] = oracle_rand64_u64(&master);
+    size_t nj = restart_end > restart_begin ? restart_end - restart_begin : 0;
+    restart_job *jobs = (restart_job *)calloc(nj ? nj : 1, sizeof(restart_job));
+    for (size_t i = 0; i < nj; i++) {
+        uint32_t r = restart_begin + (uint32_t)i;
+        jobs[i].ds = ds;
+        jobs[i].p = p;
+        jobs[i].measure = measure;
+        jobs[i].depth = depth;
+        jobs[i].norms = norms;
+        jobs[i].fids = fids;
+        jobs[i].nf = nf;
+        jobs[i].dim = dim;
+        jobs[i].child_seed = child[r];
+        jobs[i].out_w = out_weights + (size_t)r * dim;
+    }
+    job_queue q;
+    q.jobs = jobs;
+    q.njobs = nj;
+    q.next = 0;
+    pthread_mutex_init(&q.mu, NULL);
+    if (threads < 1) threads = 1;
+    if (threads > nj) threads = nj ? nj : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (size_t t = 0; t < threads; t++) pthread_create(&th[t], NULL, worker, &q);
+    for (size_t t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    int err = 0;
+    for (size_t i = 0; i < nj; i++) {
+        uint32_t r = restart_begin + (uint32_t)i;
+        out_scores[r] = jobs[i].out_score;
+        out_evals[r] = jobs[i].n_evals;
+        err |= jobs[i].err;
+    }
+    pthread_mutex_destroy(&q.mu);
+    free(th);
+    free(jobs);
+    free(child);
+    return err;
+}
+
+/* coordinate_ascent.rs:244-251: Iterator::max over restart-ordered history = LAST maximum */
+uint32_t oracle_select_best(const double *scores, uint32_t begin, uint32_t end) {
+    uint32_t best = begin;
+    for (uint32_t r = begin; r < end; r++)
+        if (scores[r] >= scores[best]) best = r;
+    return best;
+}
+
+/* The candidate weights one line search visits, in evaluation order (dir 0; dir -1 steps;
+ * dir +1 steps) -- coordinate_ascent.rs:145-171.  Exposed so GPU tests can check the host
+ * trainer's candidate generation bit-for-bit.  out must hold 1 + 2*iters doubles. */
+size_t oracle_ca_candidates(double orig, double step_base, double step_scale, uint32_t iters,
+                            double *out) {
+    static const int SIGN[3] = {0, -1, 1};
+    size_t n = 0;
+    for (int s = 0; s < 3; s++) {
+        double dir = (double)SIGN[s];
+        double step = step_base * dir;
+        if (orig != 0.0 && fabs(step) > 0.5 * fabs(orig)) step = step_base * fabs(orig) * dir;
+        double total = step;
+        uint32_t it_n = iters;
+        if (SIGN[s] == 0) {
+            it_n = 1;
+            total = -orig;
+        }
+        for (uint32_t it = 0; it < it_n; it++) {
+            out[n++] = orig + total;
+            step *= step_scale;
+            total += step;
+        }
+    }
+    return n;
+}
