@@ -1,0 +1,811 @@
+// extern "C" boundary of libfastrank_amd.so -- see include/fastrank.h for the contract and the
+// reference file:line each symbol replaces (src/lib.rs, src/ffi.rs, src/json_api.rs).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+#include "../../include/fastrank.h"
+#include "host.hpp"
+#include "loader.hpp"
+
+using fr::FrError;
+using frjson::Value;
+
+struct CDataset {
+    std::shared_ptr<fr::DatasetView> view;
+};
+struct CModel {
+    fr::Model actual;
+};
+struct CQRel {
+    fr::QRel actual;
+};
+
+namespace {
+
+std::mutex g_api_mu;  // one device job at a time per process (handles themselves are immutable)
+fr::TrainStats g_last_stats;
+
+// src/ffi.rs:40-43 return_string
+const void* return_string(const std::string& s) {
+    char* p = (char*)malloc(s.size() + 1);
+    memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+std::string error_envelope(const std::string& debug_context) {
+    Value o = Value::object();
+    o.set("error", Value::string("error"));
+    o.set("context", Value::string(debug_context));
+    return frjson::dump(o);
+}
+
+// src/ffi.rs:29-37 accept_str
+std::string accept_str(const char* name, const void* input) {
+    if (!input) fr::fail_str(std::string("NULL pointer: ") + name);
+    return std::string((const char*)input);
+}
+
+Value parse_json_or_fail(const std::string& text) {
+    try {
+        return frjson::parse(text.c_str());
+    } catch (const frjson::ParseError& e) {
+        fr::fail_raw(e.debug());
+    }
+}
+
+// src/ffi.rs:45-55 result_to_json
+template <typename F>
+const void* json_call(F&& body) {
+    std::string out;
+    try {
+        out = body();
+    } catch (const FrError& e) {
+        out = error_envelope(e.debug);
+    } catch (const std::exception& e) {
+        out = error_envelope(frjson::rust_debug_str(e.what()));
+    }
+    return return_string(out);
+}
+
+// src/ffi.rs:57-74 result_to_c
+template <typename T, typename F>
+const CResult* c_call(F&& body) {
+    CResult* r = (CResult*)malloc(sizeof(CResult));
+    r->error_message = nullptr;
+    r->success = nullptr;
+    try {
+        T* item = body();
+        r->success = item;
+    } catch (const FrError& e) {
+        r->error_message = return_string(error_envelope(e.debug));
+    } catch (const std::exception& e) {
+        r->error_message = return_string(error_envelope(frjson::rust_debug_str(e.what())));
+    }
+    return r;
+}
+
+// NULL on success, else envelope string
+template <typename F>
+const void* status_call(F&& body) {
+    try {
+        body();
+        return nullptr;
+    } catch (const FrError& e) {
+        return return_string(error_envelope(e.debug));
+    } catch (const std::exception& e) {
+        return return_string(error_envelope(frjson::rust_debug_str(e.what())));
+    }
+}
+
+const CDataset& require_dataset(const void* p) {
+    if (!p) fr::fail_str("Dataset pointer is null!");
+    return *(const CDataset*)p;
+}
+const CModel& require_model(const void* p) {
+    if (!p) fr::fail_str("Model pointer is null!");
+    return *(const CModel*)p;
+}
+
+Value unknown_cmd(const char* kind, const std::string& cmd) {
+    Value o = Value::object();
+    o.set("error", Value::string(kind));
+    o.set("context", Value::string(cmd));
+    return o;
+}
+
+// instances_by_query of a view: qid -> instance ids in view order (ascending for unsampled data)
+std::vector<std::pair<std::string, std::vector<uint32_t>>> instances_by_query(const fr::DatasetView& v) {
+    std::vector<std::pair<std::string, std::vector<uint32_t>>> out;
+    std::unordered_map<uint32_t, size_t> slot;
+    for (uint32_t id : v.instances) {
+        uint32_t qi = v.core->qix[id];
+        auto it = slot.find(qi);
+        if (it == slot.end()) {
+            it = slot.emplace(qi, out.size()).first;
+            out.emplace_back(v.core->qnames[qi], std::vector<uint32_t>());
+        }
+        out[it->second].second.push_back(id);
+    }
+    return out;
+}
+
+Value stats_to_json(const fr::TrainStats& s) {
+    Value o = Value::object();
+    o.set("useful_evals", Value::uint(s.useful_evals));
+    o.set("raw_evals", Value::uint(s.raw_evals));
+    o.set("ticks", Value::uint(s.ticks));
+    o.set("groups", Value::uint(s.groups));
+    o.set("seconds", Value::number(s.seconds));
+    o.set("path", Value::string(s.path));
+    o.set("restarts", Value::uint(s.restarts));
+    return o;
+}
+
+struct ParsedRequest {
+    std::string measure;
+    bool is_ca = false;
+    fr::CAParams ca;
+    bool has_qrel = false;
+    fr::QRel qrel;
+};
+
+// src/json_api.rs:13-34 TrainRequest
+ParsedRequest parse_train_request(const std::string& text) {
+    Value v = parse_json_or_fail(text);
+    if (!v.is_object()) fr::fail_raw("Error(\"invalid type: expected struct TrainRequest\", line: 1, column: 1)");
+    ParsedRequest rq;
+    const Value& m = fr::json_field(v, "measure");
+    if (!m.is_string()) fr::fail_raw("Error(\"invalid type: expected a string for measure\", line: 1, column: 1)");
+    rq.measure = m.s;
+    const auto& var = fr::json_variant(fr::json_field(v, "params"), "FastRankModelParams");
+    if (var.first == "CoordinateAscent") {
+        rq.is_ca = true;
+        rq.ca = fr::CAParams::from_json(var.second);
+    } else if (var.first == "RandomForest") {
+        rq.is_ca = false;
+    } else {
+        fr::fail_raw("Error(\"unknown variant `" + var.first +
+                     "`, expected `CoordinateAscent` or `RandomForest`\", line: 1, column: 1)");
+    }
+    const Value* j = v.find("judgments");
+    if (j && !j->is_null()) {
+        rq.has_qrel = true;
+        rq.qrel = fr::qrel_from_json(*j);
+    }
+    return rq;
+}
+
+Value random_forest_defaults_json() {
+    // src/random_forest.rs:141-157 (+ :14-20 tuple-variant wire form {"SquaredError":[]})
+    fr::Rand64 rand(0xdeadbeefULL);
+    Value p = Value::object();
+    p.set("seed", Value::uint(rand.rand_u64()));
+    p.set("quiet", Value::boolean(false));
+    p.set("num_trees", Value::uint(100));
+    p.set("weight_trees", Value::boolean(false));
+    Value sm = Value::object();
+    sm.set("SquaredError", Value::array());
+    p.set("split_method", std::move(sm));
+    p.set("instance_sampling_rate", Value::number(0.5));
+    p.set("feature_sampling_rate", Value::number(0.25));
+    p.set("min_leaf_support", Value::uint(10));
+    p.set("split_candidates", Value::uint(3));
+    p.set("max_depth", Value::uint(8));
+    return p;
+}
+
+// Rust's Display for f64: shortest round-trip digits, never exponent form
+std::string rust_display_f64(double v) {
+    if (v != v) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific);
+    std::string sci(buf, r.ptr);
+    bool neg = sci[0] == '-';
+    if (neg) sci.erase(0, 1);
+    size_t epos = sci.find('e');
+    std::string digits;
+    for (char c : sci.substr(0, epos))
+        if (c != '.') digits += c;
+    int exp10 = atoi(sci.c_str() + epos + 1);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    std::string out = neg ? "-" : "";
+    int kk = exp10 + 1;
+    if (digits == "0") return out + "0";
+    if (kk <= 0) {
+        out += "0.";
+        out.append((size_t)(-kk), '0');
+        out += digits;
+    } else if ((int)digits.size() <= kk) {
+        out += digits;
+        out.append((size_t)(kk - (int)digits.size()), '0');
+    } else {
+        out.append(digits, 0, (size_t)kk);
+        out += '.';
+        out.append(digits, (size_t)kk, std::string::npos);
+    }
+    return out;
+}
+
+fr::Model train_ca(fr::DatasetView& view, const ParsedRequest& rq, uint32_t rbegin, uint32_t rend,
+                   std::vector<fr::RestartResult>* hist_out) {
+    auto t0 = std::chrono::steady_clock::now();
+    fr::Evaluator ev = fr::make_evaluator(view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+    if (view.host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+    fr::TrainStats stats;
+    std::vector<fr::RestartResult> hist = fr::ca_train(view, ev, rq.ca, rbegin, rend, &stats);
+    stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_last_stats = stats;
+    fr::Model m;
+    if (hist_out) {
+        *hist_out = hist;
+    } else {
+        m = fr::ca_select(hist, rq.ca.output_ensemble);
+    }
+    return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+void free_str(void* p) { free(p); }
+void free_c_result(CResult* p) { free(p); }
+void free_dataset(CDataset* p) { delete p; }
+void free_model(CModel* p) { delete p; }
+void free_cqrel(CQRel* p) { delete p; }
+
+const CResult* load_cqrel(const void* data_path) {
+    return c_call<CQRel>([&]() {
+        std::string path = accept_str("data_path", data_path);
+        auto* q = new CQRel();
+        try {
+            q->actual = fr::load_qrel_file(path);
+        } catch (...) {
+            delete q;
+            throw;
+        }
+        return q;
+    });
+}
+
+const CResult* cqrel_from_json(const void* json_str) {
+    return c_call<CQRel>([&]() {
+        Value v = parse_json_or_fail(accept_str("json_str", json_str));
+        auto* q = new CQRel();
+        try {
+            q->actual = fr::qrel_from_json(v);
+        } catch (...) {
+            delete q;
+            throw;
+        }
+        return q;
+    });
+}
+
+const void* cqrel_query_json(const CQRel* cqrel, const void* query_str) {
+    return json_call([&]() {
+        if (!cqrel) fr::fail_str("cqrel pointer is null!");
+        std::string cmd = accept_str("query_str", query_str);
+        if (cmd == "to_json") return frjson::dump(fr::qrel_to_json(cqrel->actual));
+        if (cmd == "queries") {
+            Value a = Value::array();
+            for (const auto& q : cqrel->actual.queries) a.push(Value::string(q.first));
+            return frjson::dump(a);
+        }
+        const auto* docs = cqrel->actual.get(cmd);
+        if (!docs) fr::fail_str("Unknown request: " + cmd);
+        return frjson::dump(fr::qrel_query_to_json(*docs));
+    });
+}
+
+const CResult* load_ranksvm_format(void* data_path, void* feature_names_path) {
+    return c_call<CDataset>([&]() {
+        std::string path = accept_str("data_path", data_path);
+        std::map<uint32_t, std::string> names;
+        bool has_names = false;
+        if (feature_names_path) {
+            names = fr::load_feature_names(accept_str("feature_names_path", feature_names_path));
+            has_names = true;
+        }
+        auto* d = new CDataset();
+        try {
+            d->view = fr::load_ranksvm(path, has_names ? &names : nullptr);
+        } catch (...) {
+            delete d;
+            throw;
+        }
+        return d;
+    });
+}
+
+const CResult* dataset_query_sampling(CDataset* dataset, const void* queries_json_list) {
+    return c_call<CDataset>([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        Value v = parse_json_or_fail(accept_str("queries_json_list", queries_json_list));
+        if (!v.is_array()) fr::fail_raw("Error(\"invalid type: expected a sequence\", line: 1, column: 1)");
+        std::set<std::string> wanted;
+        for (const auto& x : v.arr) {
+            if (!x.is_string()) fr::fail_raw("Error(\"invalid type: expected a string\", line: 1, column: 1)");
+            wanted.insert(x.s);
+        }
+        // src/sampling.rs:117-133 with_queries
+        auto child = std::make_shared<fr::DatasetView>();
+        child->core = ds.view->core;
+        child->features = ds.view->features;
+        child->sampled = true;
+        for (auto& qi : instances_by_query(*ds.view))
+            if (wanted.count(qi.first)) child->instances.insert(child->instances.end(), qi.second.begin(), qi.second.end());
+        auto* out = new CDataset();
+        out->view = child;
+        return out;
+    });
+}
+
+const CResult* dataset_feature_sampling(CDataset* dataset, const void* feature_json_list) {
+    return c_call<CDataset>([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        Value v = parse_json_or_fail(accept_str("feature_json_list", feature_json_list));
+        if (!v.is_array()) fr::fail_raw("Error(\"invalid type: expected a sequence\", line: 1, column: 1)");
+        // src/sampling.rs:91-115 with_features
+        std::set<uint32_t> valid(ds.view->features.begin(), ds.view->features.end());
+        std::set<uint32_t> keep, missing;
+        for (const auto& x : v.arr) {
+            uint32_t fid = (uint32_t)fr::json_u64(x, "FeatureId");
+            (valid.count(fid) ? keep : missing).insert(fid);
+        }
+        if (!missing.empty()) {
+            std::string s = "Missing Features: {";
+            bool first = true;
+            for (uint32_t f : missing) {
+                if (!first) s += ", ";
+                s += "FeatureId(" + std::to_string(f) + ")";
+                first = false;
+            }
+            fr::fail_str(s + "}");
+        }
+        if (keep.empty()) fr::fail_str("No Features!");
+        auto child = std::make_shared<fr::DatasetView>();
+        child->core = ds.view->core;
+        child->features.assign(keep.begin(), keep.end());
+        child->instances = ds.view->instances;
+        child->sampled = true;
+        auto* out = new CDataset();
+        out->view = child;
+        return out;
+    });
+}
+
+const void* dataset_query_json(void* dataset, void* json_cmd_str) {
+    return json_call([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        const fr::DatasetView& v = *ds.view;
+        std::string cmd = accept_str("dataset_query_json", json_cmd_str);
+        // src/ffi.rs:144-183
+        if (cmd == "is_sampled") return std::string(v.sampled ? "true" : "false");
+        if (cmd == "num_features") return std::to_string(v.n_dim());
+        if (cmd == "feature_ids") {
+            Value a = Value::array();
+            for (uint32_t f : v.features) a.push(Value::uint(f));
+            return frjson::dump(a);
+        }
+        if (cmd == "num_instances") return std::to_string(v.instances.size());
+        if (cmd == "queries") {
+            Value a = Value::array();
+            for (auto& qi : instances_by_query(v)) a.push(Value::string(qi.first));
+            return frjson::dump(a);
+        }
+        if (cmd == "instances_by_query") {
+            Value o = Value::object();
+            for (auto& qi : instances_by_query(v)) {
+                Value a = Value::array();
+                for (uint32_t id : qi.second) a.push(Value::uint(id));
+                o.obj.emplace_back(qi.first, std::move(a));
+            }
+            return frjson::dump(o);
+        }
+        if (cmd == "feature_names") {
+            Value a = Value::array();
+            for (uint32_t f : v.features) a.push(Value::string(v.core->feature_name(f)));
+            return frjson::dump(a);
+        }
+        return frjson::dump(unknown_cmd("unknown_dataset_query_str", cmd));
+    });
+}
+
+const void* query_json(const void* json_cmd_str) {
+    return json_call([&]() {
+        std::string cmd = accept_str("query_json_str", json_cmd_str);
+        // src/ffi.rs:215-236
+        if (cmd == "coordinate_ascent_defaults" || cmd == "random_forest_defaults") {
+            Value o = Value::object();
+            o.set("measure", Value::string("ndcg"));
+            Value params = Value::object();
+            if (cmd == "coordinate_ascent_defaults")
+                params.set("CoordinateAscent", fr::CAParams::defaults().to_json());
+            else
+                params.set("RandomForest", random_forest_defaults_json());
+            o.set("params", std::move(params));
+            o.set("judgments", Value::null());
+            return frjson::dump(o);
+        }
+        return frjson::dump(unknown_cmd("unknown_query_str", cmd));
+    });
+}
+
+const CResult* make_dense_dataset_f32_f64_i64(size_t n, size_t d, const float* x, const double* y,
+                                              const int64_t* qids) {
+    return c_call<CDataset>([&]() {
+        if ((n && (!x || !y || !qids))) fr::fail_str("NULL pointer: dense dataset arrays");
+        auto* out = new CDataset();
+        try {
+            out->view = fr::make_dense(n, d, x, y, qids);
+        } catch (...) {
+            delete out;
+            throw;
+        }
+        return out;
+    });
+}
+
+const CResult* train_model(void* train_request_json, void* dataset) {
+    return c_call<CModel>([&]() {
+        // src/lib.rs:249-252: the dataset pointer is checked after the request is parsed lazily;
+        // result_train_model reports the null dataset first (src/ffi.rs:189-193)
+        const CDataset& ds = require_dataset(dataset);
+        ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
+        if (!rq.is_ca)
+            fr::fail_str(
+                "RandomForest training is outside the MI355X hot path (SURVEY.md section 8); only tree-ensemble "
+                "*scoring* is implemented. Train with CoordinateAscent or load a forest with model_from_json.");
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        auto* out = new CModel();
+        try {
+            out->actual = train_ca(*ds.view, rq, 0, rq.ca.num_restarts, nullptr);
+        } catch (...) {
+            delete out;
+            throw;
+        }
+        return out;
+    });
+}
+
+const CResult* model_from_json(const void* json_str) {
+    return c_call<CModel>([&]() {
+        Value v = parse_json_or_fail(accept_str("json_str", json_str));
+        auto* out = new CModel();
+        try {
+            out->actual = fr::model_from_json(v);
+        } catch (...) {
+            delete out;
+            throw;
+        }
+        return out;
+    });
+}
+
+const void* model_query_json(const void* model, const void* json_cmd_str) {
+    return json_call([&]() {
+        const CModel& m = require_model(model);
+        std::string cmd = accept_str("query_json", json_cmd_str);
+        if (cmd == "to_json") return frjson::dump(fr::model_to_json(m.actual));
+        return frjson::dump(unknown_cmd("unknown_dataset_query_str", cmd));  // sic: src/ffi.rs:206-209
+    });
+}
+
+const void* evaluate_by_query(const CModel* model, const CDataset* dataset, const CQRel* qrel,
+                              const void* evaluator) {
+    return json_call([&]() {
+        const CModel& m = require_model(model);
+        const CDataset& ds = require_dataset(dataset);
+        std::string name = accept_str("evaluator_name", evaluator);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
+        Value o = Value::object();
+        if (view.instances.empty()) return frjson::dump(o);
+        frdev::DeviceDataset& dev = view.device();
+        fr::score_model(view, m.actual);
+        std::string err;
+        if (!dev.metric_from_scores(ev.measure, ev.depth, ev.norms.data(), 1, false, &err)) fr::fail_str(err);
+        fr::check_flags(dev);
+        std::vector<double> vals(dev.nq());
+        if (!dev.download_per_query(1, vals.data(), &err)) fr::fail_str(err);
+        for (size_t q = 0; q < vals.size(); q++)
+            o.obj.emplace_back(view.core->qnames[view.csr_query[q]], Value::number(vals[q]));
+        return frjson::dump(o);
+    });
+}
+
+const void* predict_scores(const CModel* model, const CDataset* dataset) {
+    return json_call([&]() {
+        const CModel& m = require_model(model);
+        const CDataset& ds = require_dataset(dataset);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        if (view.instances.empty()) return std::string("{}");
+        frdev::DeviceDataset& dev = view.device();
+        fr::score_model(view, m.actual);
+        std::vector<double> scores(view.core->n, 0.0);
+        std::string err;
+        if (!dev.download_scores(0, scores.data(), scores.size(), &err)) fr::fail_str(err);
+        for (uint32_t id : view.instances)
+            if (scores[id] != scores[id]) fr::fail_str("Model.predict -> NaN");
+        // src/json_api.rs:53-72: {"<instance index>": score}
+        std::string out = "{";
+        bool first = true;
+        std::vector<uint32_t> ids = view.instances;
+        std::sort(ids.begin(), ids.end());
+        for (uint32_t id : ids) {
+            if (!first) out += ',';
+            first = false;
+            out += '"';
+            out += std::to_string(id);
+            out += "\":";
+            frjson::write_double(out, scores[id]);
+        }
+        out += '}';
+        return out;
+    });
+}
+
+const void* predict_to_trecrun(const CModel* model, const CDataset* dataset, const void* output_path,
+                               const void* system_name, size_t depth) {
+    return json_call([&]() {
+        const CModel& m = require_model(model);
+        const CDataset& ds = require_dataset(dataset);
+        std::string path = accept_str("output_path", output_path);
+        std::string sysname = accept_str("system_name", system_name);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        // src/json_api.rs:75-120
+        std::ofstream out(path);
+        if (!out) fr::fail_str("could not open " + path + " for writing");
+        size_t written = 0;
+        if (view.instances.empty()) return std::to_string(written);
+        frdev::DeviceDataset& dev = view.device();
+        fr::score_model(view, m.actual);
+        std::string err;
+        std::vector<double> norms(dev.nq(), 0.0);
+        if (!dev.metric_from_scores(frdev::M_RR, -1, norms.data(), 1, true, &err)) fr::fail_str(err);
+        fr::check_flags(dev);
+        std::vector<uint32_t> rank(dev.n());
+        if (!dev.download_rank(rank.data(), &err)) fr::fail_str(err);
+        std::vector<double> scores(view.core->n, 0.0);
+        if (!dev.download_scores(0, scores.data(), scores.size(), &err)) fr::fail_str(err);
+        const frdev::HostCSR& csr = view.host_csr();
+        const fr::DataCore& c = *view.core;
+        for (size_t q = 0; q < csr.nq; q++) {
+            const std::string& qid = c.qnames[view.csr_query[q]];
+            for (uint32_t p = csr.qoff[q]; p < csr.qoff[q + 1]; p++) {
+                size_t rk = p - csr.qoff[q] + 1;
+                if (depth > 0 && rk > depth) break;
+                uint32_t id = rank[p];
+                if (!c.has_docids || id >= c.doc_present.size() || !c.doc_present[id])
+                    fr::fail_str("Dataset does not contain document ids and therefore cannot save to trecrun!");
+                out << qid << " Q0 " << c.docids[id] << " " << rk << " " << rust_display_f64(scores[id]) << " "
+                    << sysname << "\n";
+                written++;
+            }
+            out.flush();
+        }
+        return std::to_string(written);
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// extensions
+// ------------------------------------------------------------------------------------------
+
+int fr_device_count(void) { return frdev::device_count(nullptr); }
+
+int fr_set_device(int ordinal) {
+    std::string err;
+    return frdev::set_device(ordinal, &err) ? 0 : 1;
+}
+
+const char* fr_version(void) { return "fastrank_amd 0.1.0 (fastrank C ABI 0.9.0-dev / python 0.7.0)"; }
+
+const void* fr_train_model_shard(const void* train_request_json, const CDataset* dataset, uint32_t restart_begin,
+                                 uint32_t restart_end) {
+    return json_call([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
+        if (!rq.is_ca) fr::fail_str("fr_train_model_shard: only CoordinateAscent shards by restart");
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::vector<fr::RestartResult> hist;
+        train_ca(*ds.view, rq, restart_begin, restart_end, &hist);
+        Value o = Value::object();
+        Value arr = Value::array();
+        for (const auto& h : hist) {
+            Value r = Value::object();
+            r.set("restart_id", Value::uint(h.restart_id));
+            r.set("score", Value::number(h.score));
+            Value w = Value::array();
+            for (double x : h.weights) w.push(Value::number(x));
+            r.set("weights", std::move(w));
+            arr.push(std::move(r));
+        }
+        o.set("restarts", std::move(arr));
+        o.set("stats", stats_to_json(g_last_stats));
+        return frjson::dump(o);
+    });
+}
+
+const CResult* fr_select_model(const void* restarts_json, int output_ensemble) {
+    return c_call<CModel>([&]() {
+        Value v = parse_json_or_fail(accept_str("restarts_json", restarts_json));
+        if (!v.is_array()) fr::fail_raw("Error(\"invalid type: expected a sequence\", line: 1, column: 1)");
+        std::vector<fr::RestartResult> hist;
+        for (const auto& r : v.arr) {
+            fr::RestartResult h;
+            h.restart_id = (uint32_t)fr::json_u64(fr::json_field(r, "restart_id"), "restart_id");
+            h.score = fr::json_f64(fr::json_field(r, "score"), "score");
+            for (const auto& x : fr::json_field(r, "weights").arr) h.weights.push_back(fr::json_f64(x, "weights"));
+            hist.push_back(std::move(h));
+        }
+        // restart order defines "last maximum" (src/coordinate_ascent.rs:244-251)
+        std::stable_sort(hist.begin(), hist.end(),
+                         [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });
+        auto* out = new CModel();
+        try {
+            out->actual = fr::ca_select(hist, output_ensemble != 0);
+        } catch (...) {
+            delete out;
+            throw;
+        }
+        return out;
+    });
+}
+
+const void* fr_last_train_stats(void) {
+    return json_call([&]() { return frjson::dump(stats_to_json(g_last_stats)); });
+}
+
+const void* fr_predict_scores_dense(const CModel* model, const CDataset* dataset, double* out, size_t out_len) {
+    return status_call([&]() {
+        const CModel& m = require_model(model);
+        const CDataset& ds = require_dataset(dataset);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        if (view.instances.empty()) return;
+        frdev::DeviceDataset& dev = view.device();
+        fr::score_model(view, m.actual);
+        std::string err;
+        if (!dev.download_scores(0, out, out_len, &err)) fr::fail_str(err);
+    });
+}
+
+const void* fr_evaluate_dense(const CModel* model, const CDataset* dataset, const CQRel* qrel,
+                              const void* evaluator_name, double* out_values, size_t out_len,
+                              const void** out_qids_json) {
+    return status_call([&]() {
+        const CModel& m = require_model(model);
+        const CDataset& ds = require_dataset(dataset);
+        std::string name = accept_str("evaluator_name", evaluator_name);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
+        frdev::DeviceDataset& dev = view.device();
+        if (out_len < dev.nq()) fr::fail_str("fr_evaluate_dense: output buffer too small");
+        fr::score_model(view, m.actual);
+        std::string err;
+        if (!dev.metric_from_scores(ev.measure, ev.depth, ev.norms.data(), 1, false, &err)) fr::fail_str(err);
+        fr::check_flags(dev);
+        if (!dev.download_per_query(1, out_values, &err)) fr::fail_str(err);
+        if (out_qids_json) {
+            Value a = Value::array();
+            for (size_t q = 0; q < dev.nq(); q++) a.push(Value::string(view.core->qnames[view.csr_query[q]]));
+            *out_qids_json = return_string(frjson::dump(a));
+        }
+    });
+}
+
+const void* fr_rank_order(const CModel* model, const CDataset* dataset, uint32_t* out_instance_ids, size_t n,
+                          uint64_t* out_offsets, size_t nq_plus_1) {
+    return status_call([&]() {
+        const CModel& m = require_model(model);
+        const CDataset& ds = require_dataset(dataset);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        frdev::DeviceDataset& dev = view.device();
+        if (n < dev.n() || nq_plus_1 < dev.nq() + 1) fr::fail_str("fr_rank_order: output buffers too small");
+        fr::score_model(view, m.actual);
+        std::string err;
+        std::vector<double> norms(dev.nq(), 0.0);
+        if (!dev.metric_from_scores(frdev::M_RR, -1, norms.data(), 1, true, &err)) fr::fail_str(err);
+        fr::check_flags(dev);
+        if (!dev.download_rank(out_instance_ids, &err)) fr::fail_str(err);
+        const frdev::HostCSR& csr = view.host_csr();
+        for (size_t q = 0; q <= csr.nq; q++) out_offsets[q] = csr.qoff[q];
+    });
+}
+
+size_t fr_dataset_num_queries(const CDataset* dataset) {
+    if (!dataset) return 0;
+    return dataset->view->host_csr().nq;
+}
+
+size_t fr_dataset_num_instances(const CDataset* dataset) {
+    if (!dataset) return 0;
+    return dataset->view->instances.size();
+}
+
+const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, const void* evaluator_name,
+                                   size_t n_groups, const uint32_t* features, const double* base_weights,
+                                   const uint32_t* n_cand, const double* candidates, double* out_means,
+                                   double* out_per_query) {
+    return status_call([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        std::string name = accept_str("evaluator_name", evaluator_name);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::DatasetView& view = *ds.view;
+        fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
+        frdev::DeviceDataset& dev = view.device();
+        const size_t d = dev.d();
+        std::string err;
+        for (size_t g = 0; g < n_groups; g++)
+            if (n_cand[g] == 0 || n_cand[g] > 64 || features[g] >= d)
+                fr::fail_str("fr_evaluate_candidates: malformed group");
+        if (frdev::DeviceDataset::linesearch_supported(ev.measure, ev.depth)) {
+            std::vector<frdev::LineGroup> groups(n_groups);
+            for (size_t g = 0; g < n_groups; g++) {
+                groups[g].feature = features[g];
+                groups[g].weights.assign(base_weights + g * d, base_weights + (g + 1) * d);
+                groups[g].candidates.assign(candidates + g * 64, candidates + g * 64 + n_cand[g]);
+            }
+            std::vector<double> means;
+            if (!dev.linesearch_ndcg(ev.depth, ev.norms.data(), groups, &means, &err)) fr::fail_str(err);
+            fr::check_flags(dev);
+            std::copy(means.begin(), means.end(), out_means);
+            if (out_per_query) {
+                std::vector<double> M;
+                size_t ldm = 0;
+                if (!dev.download_last_matrix(&M, &ldm, &err)) fr::fail_str(err);
+                std::copy(M.begin(), M.end(), out_per_query);
+            }
+        } else {
+            std::vector<double> w;
+            std::vector<size_t> slot;
+            for (size_t g = 0; g < n_groups; g++)
+                for (uint32_t c = 0; c < n_cand[g]; c++) {
+                    size_t off = w.size();
+                    w.insert(w.end(), base_weights + g * d, base_weights + (g + 1) * d);
+                    w[off + features[g]] = candidates[g * 64 + c];
+                    slot.push_back(g * 64 + c);
+                }
+            if (out_per_query) fr::fail_str("fr_evaluate_candidates: per-query output needs an ndcg@k (k<=20) measure");
+            std::vector<double> means;
+            fr::evaluate_means_generic(view, ev, w, slot.size(), means);
+            for (size_t g = 0; g < n_groups * 64; g++) out_means[g] = 0.0;
+            for (size_t k = 0; k < slot.size(); k++) out_means[slot[k]] = means[k];
+        }
+    });
+}
+
+void fr_profile_enable(int on) { frdev::profile_enable(on != 0); }
+void fr_profile_reset(void) { frdev::profile_reset(); }
+
+const void* fr_profile_json(void) {
+    return json_call([&]() {
+        Value a = Value::array();
+        for (const auto& s : frdev::profile_stats()) {
+            Value o = Value::object();
+            o.set("kernel", Value::string(s.name));
+            o.set("launches", Value::uint(s.launches));
+            o.set("total_ms", Value::number(s.total_ms));
+            a.push(std::move(o));
+        }
+        return frjson::dump(a);
+    });
+}
+
+int fr_synchronize(void) {
+    std::string err;
+    return frdev::device_synchronize(&err) ? 0 : 1;
+}
+
+}  // extern "C"

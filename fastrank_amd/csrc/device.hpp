@@ -1,0 +1,118 @@
+// Device-side interface of the MI355X hot path (no HIP types leak through this header).
+//
+// A DeviceDataset is the HBM-resident form of one reference `RankingDataset` view
+// (src/dense_dataset.rs:11-20, src/dataset.rs:101-106):
+//   * documents regrouped by query (CSR), and inside each query stored in REVERSE tie-break
+//     order (gain desc, instance-id desc) so that "later document wins score ties" reproduces
+//     the reference's (score desc, gain asc, id asc) total order (src/evaluators.rs:34-49);
+//   * features column-major f32 [D][ld] (ld = N rounded up to 64) for coalesced lane=doc reads;
+//   * per-document gain (f32), 2^gain-1 (f64, host libm like the reference), relevance flag;
+//   * per-query offsets, a longest-first query schedule, log2(i+2) discount table.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace frdev {
+
+enum Measure : int { M_NDCG = 0, M_AP = 1, M_RR = 2 };
+
+// error bits raised by kernels (the reference panics in these cases)
+enum : int {
+    FLAG_NAN_SCORE = 1,        // src/model.rs:49  "Model.predict -> NaN"
+    FLAG_ACTUAL_GT_IDEAL = 2,  // src/evaluators.rs:368-374
+};
+
+struct HostCSR {
+    size_t n = 0, d = 0, nq = 0;
+    const float* x = nullptr;     // row-major base matrix, stride d
+    std::vector<uint32_t> perm;   // CSR position -> row in x (original InstanceId)
+    std::vector<uint32_t> qoff;   // [nq+1]
+    std::vector<float> gain;      // [n] by CSR position
+};
+
+struct FlatTrees {
+    // node k: fid<0 => leaf with value `split`; else go lhs if f64(x[fid]) <= split else rhs
+    std::vector<int32_t> fid, lhs, rhs;
+    std::vector<double> split;
+    std::vector<int32_t> root;    // per tree
+    std::vector<double> weight;   // per tree (ignored when raw_single)
+    bool raw_single = false;      // a bare DecisionTree model: output = leaf value
+};
+
+// One line-search group: every candidate shares (feature f, base weights w) and differs only in
+// the weight of f (src/coordinate_ascent.rs:131-171).
+struct LineGroup {
+    uint32_t feature = 0;
+    std::vector<double> weights;     // [d] base weights (entry `feature` ignored)
+    std::vector<double> candidates;  // <= 64 values for w[feature], in evaluation order
+};
+
+struct KernelStat {
+    std::string name;
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+class DeviceDataset {
+  public:
+    static std::shared_ptr<DeviceDataset> create(const HostCSR& csr, std::string* err);
+    ~DeviceDataset();
+
+    size_t n() const;
+    size_t d() const;
+    size_t nq() const;
+    size_t max_query_len() const;
+    size_t hbm_bytes() const;
+
+    // --- scoring into the internal score buffer (slot b of B, CSR order) ---------------------
+    // weights: B vectors of length d (row-major), exact reference dot product.
+    bool score_linear(size_t B, const double* weights, std::string* err);
+    bool score_single_feature(uint32_t fid, double dir, std::string* err);
+    bool score_trees(const FlatTrees& trees, std::string* err);
+    // out += w * tmp (unfused), used for mixed ensembles (src/model.rs:104-112)
+    bool ensemble_begin(std::string* err);                 // acc = 0
+    bool ensemble_accumulate(double w, std::string* err);  // acc = acc + w * slot0
+    bool ensemble_finish(std::string* err);                // slot0 = acc
+
+    // copy slot b back, scattered to original instance ids: out[perm[p]] = score[p]
+    bool download_scores(size_t b, double* out_by_instance, size_t out_len, std::string* err);
+
+    // --- metrics -------------------------------------------------------------------------------
+    // per-query metric of the B score slots -> M[q][b]; norms[nq]: NDCG ideal (NaN=None) /
+    // AP num_relevant (0=absent).  depth<0 = None.
+    bool metric_from_scores(int measure, int64_t depth, const double* norms, size_t B,
+                            bool want_rank, std::string* err);
+    bool download_per_query(size_t B, double* out /*[nq*B], q-major*/, std::string* err);
+    bool download_rank(uint32_t* out_instance_ids /*[n] grouped by query, rank order*/, std::string* err);
+    // mean over queries of each of the last result's columns (sequential sum in query order)
+    bool reduce_means(size_t ncols, double* out_means, std::string* err);
+
+    // --- fused line search (NDCG@k, k <= 20) --------------------------------------------------
+    static bool linesearch_supported(int measure, int64_t depth);
+    // evaluates every candidate of every group; means[g*64 + c]
+    bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
+                         std::vector<double>* means, std::string* err);
+    // column stride of the last linesearch result (for download_per_query-style inspection)
+    size_t last_ldm() const;
+    bool download_last_matrix(std::vector<double>* out, size_t* ldm, std::string* err);
+
+    int take_flags();  // returns and clears the accumulated kernel error bits
+
+  private:
+    DeviceDataset();
+    struct Impl;
+    Impl* impl_;
+};
+
+// process-wide helpers -------------------------------------------------------------------------
+int device_count(std::string* err);
+bool set_device(int ordinal, std::string* err);
+void profile_enable(bool on);
+void profile_reset();
+std::vector<KernelStat> profile_stats();
+bool device_synchronize(std::string* err);
+
+}  // namespace frdev

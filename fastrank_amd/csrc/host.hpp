@@ -1,0 +1,899 @@
+// Host side of the fastrank hot path: data model, evaluator set-up, model scoring dispatch and
+// the coordinate-ascent trainer.  All arithmetic that decides a ranking runs on the device
+// (device.hip); the host keeps the reference's *sequential control semantics*
+// (src/coordinate_ascent.rs:87-254) and feeds the device batches of candidates.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "device.hpp"
+#include "json.hpp"
+
+namespace fr {
+
+using frjson::Value;
+
+// Error carried to the C boundary; `debug` is already in Rust `{:?}` form (src/ffi.rs:45-74).
+struct FrError {
+    std::string debug;
+};
+[[noreturn]] inline void fail_str(const std::string& msg) { throw FrError{frjson::rust_debug_str(msg)}; }
+[[noreturn]] inline void fail_raw(const std::string& debug) { throw FrError{debug}; }
+
+// ---------------------------------------------------------------------------------------------
+// Rand64 -- oorandom =11.1.0 (Cargo.toml:18-19), third-party, source absent from the reference
+// tree: restated from the crate's published PCG algorithm.  Seed->trajectory parity with the
+// Rust build is UNPINNED (DESIGN.md "Parity status").
+// ---------------------------------------------------------------------------------------------
+class Rand64 {
+  public:
+    explicit Rand64(uint64_t seed) {
+        state_ = 0;
+        inc_ = (default_inc() << 1) | 1;
+        (void)rand_u64();
+        state_ += (u128)seed;
+        (void)rand_u64();
+    }
+    uint64_t rand_u64() {
+        u128 old = state_;
+        state_ = old * multiplier() + inc_;
+        uint64_t xorshifted = (uint64_t)(((old >> 29) ^ old) >> 58);
+        uint32_t rot = (uint32_t)(old >> 122);
+        return (xorshifted >> rot) | (xorshifted << ((64 - rot) & 63));
+    }
+    double rand_float() {
+        uint64_t u = rand_u64() >> (64 - 54);
+        return (double)u * (1.0 / 18014398509481984.0);
+    }
+    uint64_t rand_range(uint64_t lo, uint64_t hi) {
+        uint64_t s = hi - lo;
+        u128 m = (u128)rand_u64() * (u128)s;
+        uint64_t leftover = (uint64_t)m;
+        if (leftover < s) {
+            uint64_t threshold = (0 - s) % s;
+            while (leftover < threshold) {
+                m = (u128)rand_u64() * (u128)s;
+                leftover = (uint64_t)m;
+            }
+        }
+        return (uint64_t)(m >> 64) + lo;
+    }
+
+  private:
+    typedef unsigned __int128 u128;
+    static u128 multiplier() { return (((u128)2549297995355413924ULL) << 64) | (u128)4865540595714422341ULL; }
+    static u128 default_inc() { return (((u128)0x2FE0E169FFBD06E3ULL) << 64) | (u128)0x5BC307BD4D2F814FULL; }
+    u128 state_, inc_;
+};
+
+// src/randutil.rs:21-27
+template <typename T>
+inline void shuffle(std::vector<T>& v, Rand64& rand) {
+    uint64_t n = v.size();
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t j = rand.rand_range(i, n);
+        std::swap(v[i], v[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Models (src/model.rs:10-112) and their serde wire form
+// ---------------------------------------------------------------------------------------------
+struct TreeNode {
+    bool leaf = true;
+    double value = 0.0;  // leaf value or split threshold
+    uint32_t fid = 0;
+    std::unique_ptr<TreeNode> lhs, rhs;
+};
+
+struct Model {
+    enum Kind { SingleFeature, Linear, DecisionTree, Ensemble } kind = Linear;
+    uint32_t fid = 0;
+    double dir = 0.0;
+    std::vector<double> weights;
+    std::shared_ptr<TreeNode> tree;
+    std::vector<double> ens_weights;
+    std::vector<Model> members;
+};
+
+inline double json_f64(const Value& v, const char* what) {
+    if (!v.is_number()) fail_raw(std::string("Error(\"invalid type: expected f64 for ") + what + "\", line: 0, column: 0)");
+    return v.as_double();
+}
+inline uint64_t json_u64(const Value& v, const char* what) {
+    if (v.kind == Value::UInt) return v.u;
+    if (v.kind == Value::Int && v.i >= 0) return (uint64_t)v.i;
+    fail_raw(std::string("Error(\"invalid type: expected unsigned integer for ") + what + "\", line: 0, column: 0)");
+}
+inline bool json_bool(const Value& v, const char* what) {
+    if (v.kind != Value::Bool) fail_raw(std::string("Error(\"invalid type: expected a boolean for ") + what + "\", line: 0, column: 0)");
+    return v.b;
+}
+inline const Value& json_field(const Value& obj, const char* key) {
+    const Value* f = obj.find(key);
+    if (!f) fail_raw(std::string("Error(\"missing field `") + key + "`\", line: 0, column: 0)");
+    return *f;
+}
+// serde externally-tagged enum: {"Variant": payload}
+inline const frjson::Member& json_variant(const Value& v, const char* what) {
+    if (!v.is_object() || v.obj.size() != 1)
+        fail_raw(std::string("Error(\"expected a single-key map for enum ") + what + "\", line: 0, column: 0)");
+    return v.obj[0];
+}
+
+inline std::unique_ptr<TreeNode> tree_from_json(const Value& v) {
+    const auto& var = json_variant(v, "TreeNode");
+    auto node = std::make_unique<TreeNode>();
+    if (var.first == "LeafNode") {
+        node->leaf = true;
+        node->value = json_f64(var.second, "LeafNode");
+    } else if (var.first == "FeatureSplit") {
+        node->leaf = false;
+        node->fid = (uint32_t)json_u64(json_field(var.second, "fid"), "fid");
+        node->value = json_f64(json_field(var.second, "split"), "split");
+        node->lhs = tree_from_json(json_field(var.second, "lhs"));
+        node->rhs = tree_from_json(json_field(var.second, "rhs"));
+    } else {
+        fail_raw("Error(\"unknown variant `" + var.first + "`, expected `FeatureSplit` or `LeafNode`\", line: 0, column: 0)");
+    }
+    return node;
+}
+
+inline Value tree_to_json(const TreeNode& n) {
+    Value v = Value::object();
+    if (n.leaf) {
+        v.set("LeafNode", Value::number(n.value));
+    } else {
+        Value fs = Value::object();
+        fs.set("fid", Value::uint(n.fid));
+        fs.set("split", Value::number(n.value));
+        fs.set("lhs", tree_to_json(*n.lhs));
+        fs.set("rhs", tree_to_json(*n.rhs));
+        v.set("FeatureSplit", std::move(fs));
+    }
+    return v;
+}
+
+inline Model model_from_json(const Value& v) {
+    const auto& var = json_variant(v, "ModelEnum");
+    Model m;
+    if (var.first == "Linear") {
+        m.kind = Model::Linear;
+        const Value& w = json_field(var.second, "weights");
+        if (!w.is_array()) fail_raw("Error(\"invalid type: expected a sequence for weights\", line: 0, column: 0)");
+        for (const auto& x : w.arr) m.weights.push_back(json_f64(x, "weights"));
+    } else if (var.first == "SingleFeature") {
+        m.kind = Model::SingleFeature;
+        m.fid = (uint32_t)json_u64(json_field(var.second, "fid"), "fid");
+        m.dir = json_f64(json_field(var.second, "dir"), "dir");
+    } else if (var.first == "DecisionTree") {
+        m.kind = Model::DecisionTree;
+        m.tree = std::shared_ptr<TreeNode>(tree_from_json(var.second).release());
+    } else if (var.first == "Ensemble") {
+        m.kind = Model::Ensemble;
+        const Value& w = json_field(var.second, "weights");
+        const Value& ms = json_field(var.second, "models");
+        if (!w.is_array() || !ms.is_array())
+            fail_raw("Error(\"invalid type: expected sequences in Ensemble\", line: 0, column: 0)");
+        for (const auto& x : w.arr) m.ens_weights.push_back(json_f64(x, "weights"));
+        for (const auto& x : ms.arr) m.members.push_back(model_from_json(x));
+    } else {
+        fail_raw("Error(\"unknown variant `" + var.first +
+                 "`, expected one of `SingleFeature`, `Linear`, `DecisionTree`, `Ensemble`\", line: 0, column: 0)");
+    }
+    return m;
+}
+
+inline Value model_to_json(const Model& m) {
+    Value v = Value::object();
+    switch (m.kind) {
+        case Model::Linear: {
+            Value inner = Value::object();
+            Value w = Value::array();
+            for (double x : m.weights) w.push(Value::number(x));
+            inner.set("weights", std::move(w));
+            v.set("Linear", std::move(inner));
+            break;
+        }
+        case Model::SingleFeature: {
+            Value inner = Value::object();
+            inner.set("fid", Value::uint(m.fid));
+            inner.set("dir", Value::number(m.dir));
+            v.set("SingleFeature", std::move(inner));
+            break;
+        }
+        case Model::DecisionTree:
+            v.set("DecisionTree", tree_to_json(*m.tree));
+            break;
+        case Model::Ensemble: {
+            Value inner = Value::object();
+            Value w = Value::array();
+            for (double x : m.ens_weights) w.push(Value::number(x));
+            Value ms = Value::array();
+            for (const auto& mm : m.members) ms.push(model_to_json(mm));
+            inner.set("weights", std::move(w));
+            inner.set("models", std::move(ms));
+            v.set("Ensemble", std::move(inner));
+            break;
+        }
+    }
+    return v;
+}
+
+inline int32_t flatten_tree(const TreeNode& n, frdev::FlatTrees& out) {
+    int32_t idx = (int32_t)out.fid.size();
+    out.fid.push_back(-1);
+    out.split.push_back(n.value);
+    out.lhs.push_back(-1);
+    out.rhs.push_back(-1);
+    if (!n.leaf) {
+        out.fid[idx] = (int32_t)n.fid;
+        int32_t l = flatten_tree(*n.lhs, out);
+        int32_t r = flatten_tree(*n.rhs, out);
+        out.lhs[idx] = l;
+        out.rhs[idx] = r;
+    }
+    return idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Judgments (src/qrel.rs)
+// ---------------------------------------------------------------------------------------------
+struct QRel {
+    // qid -> (docid -> gain); insertion order kept for stable JSON
+    std::vector<std::pair<std::string, std::vector<std::pair<std::string, float>>>> queries;
+    std::unordered_map<std::string, size_t> index;
+
+    const std::vector<std::pair<std::string, float>>* get(const std::string& qid) const {
+        auto it = index.find(qid);
+        return it == index.end() ? nullptr : &queries[it->second].second;
+    }
+    void insert(const std::string& qid, const std::string& docid, float gain) {
+        auto it = index.find(qid);
+        size_t k;
+        if (it == index.end()) {
+            k = queries.size();
+            index.emplace(qid, k);
+            queries.emplace_back(qid, std::vector<std::pair<std::string, float>>());
+        } else {
+            k = it->second;
+        }
+        for (auto& dg : queries[k].second)
+            if (dg.first == docid) {
+                dg.second = gain;
+                return;
+            }
+        queries[k].second.emplace_back(docid, gain);
+    }
+    void ensure_query(const std::string& qid) {
+        if (index.find(qid) == index.end()) {
+            index.emplace(qid, queries.size());
+            queries.emplace_back(qid, std::vector<std::pair<std::string, float>>());
+        }
+    }
+};
+
+inline QRel qrel_from_json(const Value& v) {
+    if (!v.is_object()) fail_raw("Error(\"invalid type: expected a map\", line: 1, column: 1)");
+    QRel q;
+    for (const auto& qm : v.obj) {
+        if (!qm.second.is_object()) fail_raw("Error(\"invalid type: expected a map\", line: 1, column: 1)");
+        q.ensure_query(qm.first);
+        for (const auto& dm : qm.second.obj) {
+            double g = json_f64(dm.second, "gain");
+            q.insert(qm.first, dm.first, (float)g);
+        }
+    }
+    return q;
+}
+
+inline Value qrel_query_to_json(const std::vector<std::pair<std::string, float>>& docs) {
+    Value o = Value::object();
+    for (const auto& dg : docs) o.obj.emplace_back(dg.first, Value::number32(dg.second));
+    return o;
+}
+
+inline Value qrel_to_json(const QRel& q) {
+    Value o = Value::object();
+    for (const auto& qq : q.queries) o.obj.emplace_back(qq.first, qrel_query_to_json(qq.second));
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Datasets
+// ---------------------------------------------------------------------------------------------
+struct DataCore {
+    size_t n = 0, d = 0;          // instances, n_dim (matrix columns)
+    const float* x = nullptr;     // row-major n x d (borrowed or -> x_own)
+    std::vector<float> x_own;
+    std::vector<float> gain;      // f32 gain per instance (dense_dataset.rs:114-123: ys[i] as f32)
+    std::vector<uint32_t> qix;    // per-instance query index
+    std::vector<std::string> qnames;  // query index -> qid string (first-appearance order)
+    bool has_docids = false;
+    std::vector<std::string> docids;
+    std::vector<uint8_t> doc_present;
+    std::vector<uint32_t> features;   // feature ids present (ascending)
+    std::map<uint32_t, std::string> feature_names;
+    bool is_dense_borrowed = false;
+
+    std::string feature_name(uint32_t fid) const {
+        auto it = feature_names.find(fid);
+        return it == feature_names.end() ? std::to_string(fid) : it->second;
+    }
+};
+
+struct Evaluator {
+    int measure = frdev::M_NDCG;
+    int64_t depth = -1;
+    std::string name;
+    std::vector<double> norms;  // per CSR query
+};
+
+struct DatasetView {
+    std::shared_ptr<DataCore> core;
+    std::vector<uint32_t> features;   // feature ids visible to trainers
+    std::vector<uint32_t> instances;  // instance ids of this view, iteration order
+    bool sampled = false;
+
+    // lazily built device form
+    std::mutex mu;
+    bool csr_built = false;
+    frdev::HostCSR csr;
+    std::vector<uint32_t> csr_query;  // CSR query -> core query index
+    std::shared_ptr<frdev::DeviceDataset> dev;
+
+    uint32_t n_dim() const { return sampled ? (uint32_t)features.size() : (uint32_t)core->d; }
+
+    void build_csr() {
+        if (csr_built) return;
+        const DataCore& c = *core;
+        std::unordered_map<uint32_t, uint32_t> slot;  // core query index -> CSR query
+        std::vector<std::vector<uint32_t>> groups;
+        for (uint32_t id : instances) {
+            uint32_t qi = c.qix[id];
+            auto it = slot.find(qi);
+            if (it == slot.end()) {
+                it = slot.emplace(qi, (uint32_t)groups.size()).first;
+                groups.emplace_back();
+                csr_query.push_back(qi);
+            }
+            groups[it->second].push_back(id);
+        }
+        csr.n = instances.size();
+        csr.d = c.d;
+        csr.nq = groups.size();
+        csr.x = c.x;
+        csr.perm.reserve(csr.n);
+        csr.gain.reserve(csr.n);
+        csr.qoff.assign(1, 0);
+        for (auto& g : groups) {
+            // reverse tie-break layout: gain desc, instance id desc (device.hpp header comment)
+            std::sort(g.begin(), g.end(), [&](uint32_t a, uint32_t b) {
+                float ga = c.gain[a], gb = c.gain[b];
+                if (ga != gb) return ga > gb;
+                return a > b;
+            });
+            for (uint32_t id : g) {
+                csr.perm.push_back(id);
+                csr.gain.push_back(c.gain[id]);
+            }
+            csr.qoff.push_back((uint32_t)csr.perm.size());
+        }
+        csr_built = true;
+    }
+
+    frdev::DeviceDataset& device() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev) return *dev;
+        build_csr();
+        for (size_t p = 0; p < csr.n; p++)
+            if (csr.gain[p] != csr.gain[p]) fail_str("NaN in ys[" + std::to_string(csr.perm[p]) + "]");
+        std::string err;
+        dev = frdev::DeviceDataset::create(csr, &err);
+        if (!dev) fail_str(err);
+        return *dev;
+    }
+    const frdev::HostCSR& host_csr() {
+        std::lock_guard<std::mutex> lk(mu);
+        build_csr();
+        return csr;
+    }
+};
+
+// src/dense_dataset.rs:28-55
+inline std::shared_ptr<DatasetView> make_dense(size_t n, size_t d, const float* x, const double* y,
+                                               const int64_t* qids) {
+    auto core = std::make_shared<DataCore>();
+    core->n = n;
+    core->d = d;
+    core->x = x;
+    core->is_dense_borrowed = true;
+    core->gain.resize(n);
+    core->qix.resize(n);
+    std::unordered_map<uint32_t, uint32_t> seen;
+    for (size_t i = 0; i < n; i++) {
+        int64_t q = qids[i];
+        if (q < 0 || q > (int64_t)UINT32_MAX) fail_raw("TryFromIntError(())");  // u32::try_from(i64)?
+        auto it = seen.find((uint32_t)q);
+        if (it == seen.end()) {
+            it = seen.emplace((uint32_t)q, (uint32_t)core->qnames.size()).first;
+            core->qnames.push_back(std::to_string((uint32_t)q));
+        }
+        core->qix[i] = it->second;
+        core->gain[i] = (float)y[i];
+    }
+    for (size_t j = 0; j < d; j++) core->features.push_back((uint32_t)j);
+    auto view = std::make_shared<DatasetView>();
+    view->core = core;
+    view->features = core->features;
+    view->instances.resize(n);
+    for (size_t i = 0; i < n; i++) view->instances[i] = (uint32_t)i;
+    return view;
+}
+
+// src/evaluators.rs:255-272 on gains already sorted descending; depth<0 = None
+inline double ideal_dcg_sorted_desc(const std::vector<float>& g, int64_t depth) {
+    size_t len = depth >= 0 ? (size_t)depth : g.size();
+    double dcg = 0.0;
+    for (size_t i = 0; i < len; i++) {
+        double gain = i < g.size() ? (double)g[i] : 0.0;
+        double term = (std::pow(2.0, gain) - 1.0) / std::log2((double)i + 2.0);
+        dcg = dcg + term;
+    }
+    return dcg;
+}
+
+// src/evaluators.rs:132-155 (+ NDCG::new :303-340, AveragePrecision::new :389-419)
+inline Evaluator make_evaluator(DatasetView& view, const std::string& orig_name, const QRel* qrel) {
+    Evaluator ev;
+    std::string name = orig_name;
+    size_t at = orig_name.find('@');
+    if (at != std::string::npos) {
+        std::string rhs = orig_name.substr(at);
+        std::string num = rhs.substr(1);
+        bool ok = !num.empty();
+        size_t k = (num.size() > 1 && num[0] == '+') ? 1 : 0;
+        for (size_t t = k; t < num.size(); t++) ok = ok && num[t] >= '0' && num[t] <= '9';
+        if (ok && num.size() - k > 18) ok = false;
+        if (!ok) fail_str("Couldn't parse after the @ in \"" + orig_name + "\": " + rhs);
+        ev.depth = (int64_t)std::stoull(num.substr(k));
+        name = orig_name.substr(0, at);
+    }
+    for (auto& ch : name) ch = (char)std::tolower((unsigned char)ch);
+    if (name == "ap" || name == "map") {
+        ev.measure = frdev::M_AP;
+        ev.name = "AP";
+    } else if (name == "rr" || name == "mrr") {
+        ev.measure = frdev::M_RR;
+        ev.name = "RR";
+    } else if (name == "ndcg") {
+        ev.measure = frdev::M_NDCG;
+        ev.name = ev.depth >= 0 ? "NDCG@" + std::to_string(ev.depth) : "NDCG";
+    } else {
+        fail_str("Invalid training measure: \"" + orig_name + "\"");
+    }
+    const frdev::HostCSR& csr = view.host_csr();
+    const DataCore& c = *view.core;
+    ev.norms.assign(csr.nq, 0.0);
+    for (size_t q = 0; q < csr.nq; q++) {
+        const std::string& qid = c.qnames[view.csr_query[q]];
+        const std::vector<std::pair<std::string, float>>* judged = qrel ? qrel->get(qid) : nullptr;
+        if (ev.measure == frdev::M_NDCG) {
+            std::vector<float> gains;
+            if (judged) {
+                for (const auto& dg : *judged)
+                    if (dg.second > 0.0f) gains.push_back(dg.second);  // qrel.rs:33-39 gain_vector
+                std::sort(gains.begin(), gains.end(), [](float a, float b) { return a > b; });
+            } else {
+                // the view's docs are stored gain-descending already
+                gains.assign(csr.gain.begin() + csr.qoff[q], csr.gain.begin() + csr.qoff[q + 1]);
+            }
+            size_t pos = 0;
+            for (float g : gains) pos += g > 0.0f;
+            ev.norms[q] = pos == 0 ? std::nan("") : ideal_dcg_sorted_desc(gains, ev.depth);
+        } else if (ev.measure == frdev::M_AP) {
+            uint32_t nr = 0;
+            if (judged) {
+                for (const auto& dg : *judged) nr += dg.second > 0.0f;
+            } else {
+                for (uint32_t p = csr.qoff[q]; p < csr.qoff[q + 1]; p++) nr += csr.gain[p] > 0.0f;
+            }
+            ev.norms[q] = (double)nr;  // 0 => kernel falls back to the ranked list's own count
+        }
+    }
+    return ev;
+}
+
+inline void check_flags(frdev::DeviceDataset& dev) {
+    int fl = dev.take_flags();
+    if (fl & frdev::FLAG_NAN_SCORE) fail_str("Model.predict -> NaN");  // src/model.rs:49
+    if (fl & frdev::FLAG_ACTUAL_GT_IDEAL)
+        fail_str("actual DCG exceeds ideal DCG for some query (the reference panics here, src/evaluators.rs:368-374)");
+}
+
+#define FR_DEV(call)                      \
+    do {                                  \
+        std::string _err;                 \
+        if (!(call)) fr::fail_str(_err);  \
+    } while (0)
+
+// Score `model` for every document of the view into device score slot 0.
+inline void score_model(DatasetView& view, const Model& m) {
+    frdev::DeviceDataset& dev = view.device();
+    std::string _err;
+    switch (m.kind) {
+        case Model::Linear: {
+            std::vector<double> w(dev.d(), 0.0);
+            for (size_t j = 0; j < w.size() && j < m.weights.size(); j++) w[j] = m.weights[j];
+            if (!dev.score_linear(1, w.data(), &_err)) fail_str(_err);
+            break;
+        }
+        case Model::SingleFeature:
+            if (!dev.score_single_feature(m.fid, m.dir, &_err)) fail_str(_err);
+            break;
+        case Model::DecisionTree: {
+            frdev::FlatTrees ft;
+            ft.raw_single = true;
+            ft.root.push_back(flatten_tree(*m.tree, ft));
+            ft.weight.push_back(1.0);
+            if (!dev.score_trees(ft, &_err)) fail_str(_err);
+            break;
+        }
+        case Model::Ensemble: {
+            bool all_trees = !m.members.empty();
+            for (const auto& mm : m.members) all_trees = all_trees && mm.kind == Model::DecisionTree;
+            if (all_trees) {
+                frdev::FlatTrees ft;
+                for (size_t t = 0; t < m.members.size(); t++) {
+                    ft.root.push_back(flatten_tree(*m.members[t].tree, ft));
+                    ft.weight.push_back(t < m.ens_weights.size() ? m.ens_weights[t] : 0.0);
+                }
+                // zip(weights, models) stops at the shorter (src/model.rs:106)
+                size_t nt = std::min(m.members.size(), m.ens_weights.size());
+                ft.root.resize(nt);
+                ft.weight.resize(nt);
+                if (!dev.score_trees(ft, &_err)) fail_str(_err);
+            } else {
+                if (!dev.ensemble_begin(&_err)) fail_str(_err);
+                size_t nt = std::min(m.members.size(), m.ens_weights.size());
+                for (size_t t = 0; t < nt; t++) {
+                    const Model& mm = m.members[t];
+                    if (mm.kind == Model::Ensemble) {
+                        bool trees = !mm.members.empty();
+                        for (const auto& x : mm.members) trees = trees && x.kind == Model::DecisionTree;
+                        if (!trees)
+                            fail_str("nested mixed ensembles are not supported by the MI355X scoring path");
+                    }
+                    score_model(view, mm);
+                    if (!dev.ensemble_accumulate(m.ens_weights[t], &_err)) fail_str(_err);
+                }
+                if (!dev.ensemble_finish(&_err)) fail_str(_err);
+            }
+            break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coordinate ascent (src/coordinate_ascent.rs)
+// ---------------------------------------------------------------------------------------------
+struct CAParams {
+    uint32_t num_restarts = 5;
+    uint32_t num_max_iterations = 25;
+    double step_base = 0.05;
+    double step_scale = 2.0;
+    double tolerance = 0.001;
+    uint64_t seed = 0;
+    bool normalize = true;
+    bool quiet = false;
+    bool init_random = true;
+    bool output_ensemble = false;
+
+    static CAParams defaults() {
+        CAParams p;
+        Rand64 rand(0xdeadbeefULL);
+        p.seed = rand.rand_u64();  // coordinate_ascent.rs:27,34
+        return p;
+    }
+    static CAParams from_json(const Value& v) {
+        CAParams p;
+        p.num_restarts = (uint32_t)json_u64(json_field(v, "num_restarts"), "num_restarts");
+        p.num_max_iterations = (uint32_t)json_u64(json_field(v, "num_max_iterations"), "num_max_iterations");
+        p.step_base = json_f64(json_field(v, "step_base"), "step_base");
+        p.step_scale = json_f64(json_field(v, "step_scale"), "step_scale");
+        p.tolerance = json_f64(json_field(v, "tolerance"), "tolerance");
+        p.seed = json_u64(json_field(v, "seed"), "seed");
+        p.normalize = json_bool(json_field(v, "normalize"), "normalize");
+        p.quiet = json_bool(json_field(v, "quiet"), "quiet");
+        p.init_random = json_bool(json_field(v, "init_random"), "init_random");
+        p.output_ensemble = json_bool(json_field(v, "output_ensemble"), "output_ensemble");
+        return p;
+    }
+    Value to_json() const {
+        Value o = Value::object();
+        o.set("num_restarts", Value::uint(num_restarts));
+        o.set("num_max_iterations", Value::uint(num_max_iterations));
+        o.set("step_base", Value::number(step_base));
+        o.set("step_scale", Value::number(step_scale));
+        o.set("tolerance", Value::number(tolerance));
+        o.set("seed", Value::uint(seed));
+        o.set("normalize", Value::boolean(normalize));
+        o.set("quiet", Value::boolean(quiet));
+        o.set("init_random", Value::boolean(init_random));
+        o.set("output_ensemble", Value::boolean(output_ensemble));
+        return o;
+    }
+};
+
+struct RestartResult {
+    uint32_t restart_id = 0;
+    double score = 0.0;
+    std::vector<double> weights;
+};
+
+struct TrainStats {
+    uint64_t useful_evals = 0;  // evaluate_mean calls the sequential reference would have made
+    uint64_t raw_evals = 0;     // candidates actually evaluated (incl. speculative ones)
+    uint64_t ticks = 0;         // batched launches
+    uint64_t groups = 0;
+    double seconds = 0.0;
+    std::string path;           // "fused_linesearch" | "generic_sort"
+    uint32_t restarts = 0;
+};
+
+// coordinate_ascent.rs:72-82
+inline void l1_normalize(std::vector<double>& w) {
+    double sum = 0.0;
+    for (double x : w) sum += std::fabs(x);
+    if (sum > 0.0)
+        for (double& x : w) x /= sum;
+}
+
+// Candidate weights of one line search in evaluation order (coordinate_ascent.rs:145-171):
+// block 0 = dir 0 (1 candidate), block 1 = dir -1, block 2 = dir +1.
+inline void line_candidates(double orig, const CAParams& p, std::vector<double>& out, uint32_t block_len[3]) {
+    static const int SIGN[3] = {0, -1, 1};
+    out.clear();
+    for (int s = 0; s < 3; s++) {
+        double dir = (double)SIGN[s];
+        double step = p.step_base * dir;
+        if (orig != 0.0 && std::fabs(step) > 0.5 * std::fabs(orig)) step = p.step_base * std::fabs(orig) * dir;
+        double total = step;
+        uint32_t iters = p.num_max_iterations;
+        if (SIGN[s] == 0) {
+            iters = 1;
+            total = -orig;
+        }
+        block_len[s] = iters;
+        for (uint32_t it = 0; it < iters; it++) {
+            out.push_back(orig + total);
+            step *= p.step_scale;
+            total += step;
+        }
+    }
+}
+
+// Batched evaluate_mean of arbitrary weight vectors through the general sort path.
+inline void evaluate_means_generic(DatasetView& view, const Evaluator& ev, const std::vector<double>& weights,
+                                   size_t B, std::vector<double>& means) {
+    frdev::DeviceDataset& dev = view.device();
+    const size_t d = dev.d();
+    means.assign(B, 0.0);
+    // bound the score scratch to ~2 GiB
+    size_t ld = (dev.n() + 63) / 64 * 64;
+    size_t chunk = std::max<size_t>(1, std::min<size_t>(512, (size_t(2) << 30) / (ld * sizeof(double))));
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        size_t bn = std::min(chunk, B - b0);
+        std::string _err;
+        if (!dev.score_linear(bn, weights.data() + b0 * d, &_err)) fail_str(_err);
+        if (!dev.metric_from_scores(ev.measure, ev.depth, ev.norms.data(), bn, false, &_err)) fail_str(_err);
+        if (!dev.reduce_means(bn, means.data() + b0, &_err)) fail_str(_err);
+        check_flags(dev);
+    }
+}
+
+// learn(): coordinate_ascent.rs:198-253, restarts [rbegin, rend) of num_restarts.  All live
+// restarts advance in lock step: one device launch per "feature tick" evaluates every
+// candidate of every live restart's current line search; the host then replays the
+// reference's sequential accept / early-break logic on the returned means.
+inline std::vector<RestartResult> ca_train(DatasetView& view, const Evaluator& ev, const CAParams& p,
+                                           uint32_t rbegin, uint32_t rend, TrainStats* stats) {
+    const std::vector<uint32_t>& fids = view.features;
+    if (fids.empty()) fail_str("assertion failed: data.n_dim() > 0");
+    if (view.instances.empty()) fail_str("assertion failed: !data.instances().is_empty()");
+    frdev::DeviceDataset& dev = view.device();
+    const size_t d = dev.d();
+    uint32_t model_dim = *std::max_element(fids.begin(), fids.end()) + 1;  // :93-98
+    if (model_dim > d) fail_str("feature id out of range for this dataset");
+    rend = std::min(rend, p.num_restarts);
+
+    Rand64 master(p.seed);
+    std::vector<uint64_t> child(p.num_restarts);
+    for (uint32_t r = 0; r < p.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
+
+    struct Restart {
+        uint32_t id;
+        Rand64 rand;
+        std::vector<double> best_w;  // length d (entries >= model_dim stay 0)
+        double best_score = 0.0;
+        std::vector<uint32_t> order;
+        size_t pos = 0;
+        size_t successes = 0;
+        bool done = false;
+        // current line search
+        std::vector<double> base;
+        std::vector<double> cands;
+        uint32_t block_len[3] = {0, 0, 0};
+        size_t first_group = 0;
+        double start_score = 0.0;
+        explicit Restart(uint32_t i, uint64_t seed) : id(i), rand(seed) {}
+    };
+    std::vector<Restart> rs;
+    for (uint32_t r = rbegin; r < rend; r++) rs.emplace_back(r, child[r]);
+    const size_t R = rs.size();
+    const bool fused = frdev::DeviceDataset::linesearch_supported(ev.measure, ev.depth);
+    if (stats) {
+        *stats = TrainStats();
+        stats->path = fused ? "fused_linesearch" : "generic_sort";
+        stats->restarts = (uint32_t)R;
+    }
+    if (R == 0) return {};
+
+    // initial weights + initial evaluate_mean (:104-111)
+    std::vector<double> w0(R * d, 0.0);
+    for (size_t k = 0; k < R; k++) {
+        Restart& r = rs[k];
+        r.best_w.assign(d, 0.0);
+        if (p.init_random) {
+            for (uint32_t f : fids) r.best_w[f] = r.rand.rand_float() * 2.0 - 1.0;  // :50-54
+        } else {
+            for (uint32_t f : fids) r.best_w[f] = 1.0 / (double)fids.size();  // :60-70
+        }
+        std::copy(r.best_w.begin(), r.best_w.end(), w0.begin() + k * d);
+    }
+    std::vector<double> means;
+    evaluate_means_generic(view, ev, w0, R, means);
+    for (size_t k = 0; k < R; k++) {
+        if (means[k] != means[k]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
+        rs[k].best_score = means[k];
+        if (stats) {
+            stats->useful_evals++;
+            stats->raw_evals++;
+        }
+    }
+
+    std::vector<frdev::LineGroup> groups;
+    std::vector<double> gen_w;
+    for (;;) {
+        groups.clear();
+        gen_w.clear();
+        size_t gen_B = 0;
+        bool any = false;
+        for (Restart& r : rs) {
+            if (r.done) continue;
+            any = true;
+            if (r.pos == 0 && r.order.empty()) {
+                r.order = fids;
+                shuffle(r.order, r.rand);  // :113-116
+                r.successes = 0;
+                if (!p.quiet) printf("[restart %u] shuffle features and optimize (%s=%.6f)\n", r.id, ev.name.c_str(), r.best_score);
+            }
+            uint32_t f = r.order[r.pos];
+            r.start_score = r.best_score;
+            r.base = r.best_w;
+            if (p.normalize) {
+                // l1_normalize over the model's weights (length model_dim; the rest are 0)
+                l1_normalize(r.base);
+            }
+            double orig = r.base[f];
+            line_candidates(orig, p, r.cands, r.block_len);
+            if (fused) {
+                r.first_group = groups.size();
+                for (size_t c0 = 0; c0 < r.cands.size(); c0 += 64) {
+                    frdev::LineGroup lg;
+                    lg.feature = f;
+                    lg.weights = r.base;
+                    lg.candidates.assign(r.cands.begin() + c0,
+                                         r.cands.begin() + std::min(r.cands.size(), c0 + 64));
+                    groups.push_back(std::move(lg));
+                }
+            } else {
+                r.first_group = gen_B;
+                for (double cw : r.cands) {
+                    size_t off = gen_w.size();
+                    gen_w.insert(gen_w.end(), r.base.begin(), r.base.end());
+                    gen_w[off + f] = cw;
+                    gen_B++;
+                }
+            }
+        }
+        if (!any) break;
+        if (fused) {
+            std::string _err;
+            if (!dev.linesearch_ndcg(ev.depth, ev.norms.data(), groups, &means, &_err)) fail_str(_err);
+            check_flags(dev);
+        } else {
+            evaluate_means_generic(view, ev, gen_w, gen_B, means);
+        }
+        if (stats) {
+            stats->ticks++;
+            stats->groups += fused ? groups.size() : gen_B;
+        }
+        for (Restart& r : rs) {
+            if (r.done) continue;
+            uint32_t f = r.order[r.pos];
+            // replay coordinate_ascent.rs:145-176 over the batched results
+            size_t c = 0;
+            for (int s = 0; s < 3; s++) {
+                for (uint32_t it = 0; it < r.block_len[s]; it++, c++) {
+                    double sc = fused ? means[(r.first_group + c / 64) * 64 + (c % 64)] : means[r.first_group + c];
+                    if (stats) stats->useful_evals++;
+                    if (sc == sc && sc > r.best_score) {  // core.rs:57-66: NaN rejected, strict >
+                        r.best_score = sc;
+                        r.best_w = r.base;
+                        r.best_w[f] = r.cands[c];
+                        if (!p.quiet)
+                            printf("%4u|%-16s|%9.3f|%9.3f\n", r.id, view.core->feature_name(f).c_str(), r.cands[c], sc);
+                    }
+                }
+                if (r.best_score - r.start_score > p.tolerance) break;  // :174
+            }
+            if (stats) stats->raw_evals += r.cands.size();
+            if (r.best_score - r.start_score > p.tolerance) r.successes++;  // :179-182
+            r.pos++;
+            if (r.pos == r.order.size()) {
+                if (r.successes == 0) {
+                    r.done = true;  // :185
+                } else {
+                    r.pos = 0;
+                    r.order.clear();
+                }
+            }
+        }
+    }
+    std::vector<RestartResult> out;
+    for (Restart& r : rs) {
+        RestartResult rr;
+        rr.restart_id = r.id;
+        rr.score = r.best_score;
+        rr.weights.assign(r.best_w.begin(), r.best_w.begin() + model_dim);
+        out.push_back(std::move(rr));
+    }
+    return out;
+}
+
+// coordinate_ascent.rs:232-252 selection over a restart-ordered history
+inline Model ca_select(const std::vector<RestartResult>& hist, bool output_ensemble) {
+    if (hist.empty()) fail_str("Should be at least 1 restart!");
+    if (output_ensemble && hist.size() > 1) {
+        Model ens;
+        ens.kind = Model::Ensemble;
+        for (const auto& h : hist) {
+            Model lin;
+            lin.kind = Model::Linear;
+            lin.weights = h.weights;
+            l1_normalize(lin.weights);
+            ens.ens_weights.push_back(h.score);
+            ens.members.push_back(std::move(lin));
+        }
+        return ens;
+    }
+    size_t best = 0;
+    for (size_t k = 0; k < hist.size(); k++)
+        if (hist[k].score >= hist[best].score) best = k;  // Iterator::max = last maximum
+    Model lin;
+    lin.kind = Model::Linear;
+    lin.weights = hist[best].weights;
+    return lin;
+}
+
+}  // namespace fr

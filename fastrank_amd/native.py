@@ -1,0 +1,176 @@
+"""Extensions of the C ABI that have no reference counterpart (include/fastrank.h part 2):
+dense result buffers, the batched line-search evaluator, restart-sharded multi-GPU training and
+HIP-event kernel timing.  numpy is used only to hold buffers that cross the ABI."""
+import ctypes as C
+import json
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .clib import CDataset, CModel, CQRel, _json_reply, _load, _status, _take_str, _unwrap
+
+
+def device_count() -> int:
+    return int(_load().fr_device_count())
+
+
+def set_device(ordinal: int) -> None:
+    if _load().fr_set_device(int(ordinal)) != 0:
+        raise RuntimeError("fr_set_device({}) failed".format(ordinal))
+
+
+def version() -> str:
+    return _load().fr_version().decode("utf-8")
+
+
+def synchronize() -> None:
+    if _load().fr_synchronize() != 0:
+        raise RuntimeError("device synchronize failed")
+
+
+def num_queries(dataset: CDataset) -> int:
+    return int(_load().fr_dataset_num_queries(dataset.pointer))
+
+
+def predict_scores_dense(model: CModel, dataset: CDataset, n_total: Optional[int] = None) -> np.ndarray:
+    """Scores indexed by instance id (NaN where the id is not part of a sampled dataset)."""
+    n = int(n_total if n_total is not None else _load().fr_dataset_num_instances(dataset.pointer))
+    if n_total is None and dataset.is_sampled():
+        n = 1 + max(max(ids) for ids in dataset.instances_by_query().values())
+    out = np.full(n, np.nan, dtype=np.float64)
+    _status(_load().fr_predict_scores_dense(model.pointer, dataset.pointer, out.ctypes.data, n))
+    return out
+
+
+def evaluate_dense(model: CModel, dataset: CDataset, evaluator: str, qrel: Optional[CQRel] = None) -> Tuple[List[str], np.ndarray]:
+    nq = num_queries(dataset)
+    out = np.zeros(nq, dtype=np.float64)
+    qids_ptr = C.c_void_p()
+    _status(
+        _load().fr_evaluate_dense(
+            model.pointer, dataset.pointer, None if qrel is None else qrel.pointer, evaluator.encode("utf-8"),
+            out.ctypes.data, nq, C.byref(qids_ptr),
+        )
+    )
+    return json.loads(_take_str(qids_ptr.value)), out
+
+
+def rank_order(model: CModel, dataset: CDataset) -> Tuple[np.ndarray, np.ndarray]:
+    """(instance ids grouped by query, best first; offsets[nq+1]) under the reference's
+    (score desc, gain asc, id asc) order."""
+    nq = num_queries(dataset)
+    n = int(_load().fr_dataset_num_instances(dataset.pointer))
+    ids = np.zeros(n, dtype=np.uint32)
+    offs = np.zeros(nq + 1, dtype=np.uint64)
+    _status(_load().fr_rank_order(model.pointer, dataset.pointer, ids.ctypes.data, n, offs.ctypes.data, nq + 1))
+    return ids, offs
+
+
+def evaluate_candidates(dataset: CDataset, evaluator: str, features, base_weights, candidates: List,
+                        qrel: Optional[CQRel] = None, per_query: bool = False):
+    """Batched evaluate_mean for line-search candidates.  features[g], base_weights[g][d],
+    candidates[g] = list of <=64 values for w[features[g]].  Returns means as a list of arrays
+    (and, if per_query, the [nq][G*64] matrix)."""
+    G = len(features)
+    feats = np.ascontiguousarray(features, dtype=np.uint32)
+    base = np.ascontiguousarray(base_weights, dtype=np.float64)
+    assert base.ndim == 2 and base.shape[0] == G
+    ncand = np.asarray([len(c) for c in candidates], dtype=np.uint32)
+    cand = np.zeros((G, 64), dtype=np.float64)
+    for g, c in enumerate(candidates):
+        cand[g, : len(c)] = c
+    means = np.zeros((G, 64), dtype=np.float64)
+    pq = np.zeros((num_queries(dataset), G * 64), dtype=np.float64) if per_query else None
+    _status(
+        _load().fr_evaluate_candidates(
+            dataset.pointer, None if qrel is None else qrel.pointer, evaluator.encode("utf-8"), G,
+            feats.ctypes.data, base.ctypes.data, ncand.ctypes.data, cand.ctypes.data, means.ctypes.data,
+            None if pq is None else pq.ctypes.data,
+        )
+    )
+    out = [means[g, : ncand[g]].copy() for g in range(G)]
+    return (out, pq) if per_query else out
+
+
+def profile_enable(on: bool = True) -> None:
+    _load().fr_profile_enable(1 if on else 0)
+
+
+def profile_reset() -> None:
+    _load().fr_profile_reset()
+
+
+def profile_stats() -> Dict[str, Dict[str, float]]:
+    """{kernel: {"launches", "total_ms", "avg_ms"}} measured with HIP events on the launch stream."""
+    rows = _json_reply(_load().fr_profile_json())
+    return {
+        r["kernel"]: {"launches": r["launches"], "total_ms": r["total_ms"],
+                      "avg_ms": r["total_ms"] / max(1, r["launches"])}
+        for r in rows
+    }
+
+
+def last_train_stats() -> Dict:
+    return _json_reply(_load().fr_last_train_stats())
+
+
+def train_model_shard(dataset: CDataset, train_req, restart_begin: int, restart_end: int) -> Dict:
+    """Train restarts [begin, end) of the request on this process's GPU."""
+    request = json.dumps(train_req.to_dict()).encode("utf-8")
+    return _json_reply(_load().fr_train_model_shard(request, dataset.pointer, restart_begin, restart_end))
+
+
+def select_model(restarts: List[Dict], output_ensemble: bool = False) -> CModel:
+    """src/coordinate_ascent.rs:232-252 over gathered restarts (last maximum wins ties)."""
+    payload = json.dumps(restarts).encode("utf-8")
+    return CModel(_unwrap(_load().fr_select_model(payload, 1 if output_ensemble else 0)))
+
+
+def shard_bounds(num_restarts: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition of restart ids over ranks (first ranks take the remainder)."""
+    base, rem = divmod(num_restarts, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def train_model_distributed(dataset: CDataset, train_req, group=None) -> CModel:
+    """One process per GPU: every rank holds a replica of the dataset, trains its block of random
+    restarts, then ONE all-gather of (restart_id, score, weights) over RCCL/xGMI (gloo on CPU test
+    rigs) and the same deterministic selection on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        return dataset.train_model(train_req)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    R = int(train_req.params.num_restarts)
+    begin, end = shard_bounds(R, rank, world)
+    shard = train_model_shard(dataset, train_req, begin, end)
+    mine = shard["restarts"]
+    dim = max((len(r["weights"]) for r in mine), default=0)
+    dim_t = torch.tensor([dim], dtype=torch.int64)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dim_t = dim_t.to(dev)
+    dist.all_reduce(dim_t, op=dist.ReduceOp.MAX, group=group)
+    dim = int(dim_t.item())
+    per_rank = (R + world - 1) // world
+    # fixed-size record per restart slot: [valid, restart_id, score, w_0..w_dim-1]
+    buf = torch.zeros((per_rank, 3 + dim), dtype=torch.float64)
+    for k, r in enumerate(mine):
+        buf[k, 0] = 1.0
+        buf[k, 1] = float(r["restart_id"])
+        buf[k, 2] = r["score"]
+        buf[k, 3 : 3 + len(r["weights"])] = torch.tensor(r["weights"], dtype=torch.float64)
+    buf = buf.to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    restarts = []
+    for t in gathered:
+        for row in t.cpu().tolist():
+            if row[0] == 1.0:
+                restarts.append({"restart_id": int(row[1]), "score": row[2], "weights": row[3:]})
+    restarts.sort(key=lambda r: r["restart_id"])
+    model = select_model(restarts, bool(train_req.params.output_ensemble))
+    model.params = train_req
+    return model

@@ -1,0 +1,165 @@
+/*
+ * fastrank.h -- C ABI of libfastrank_amd.so, the MI355X-native drop-in for the fastrank cdylib.
+ *
+ * Part 1 re-declares, symbol for symbol, the `extern "C"` surface the reference exports from
+ * src/lib.rs (file:line cited per entry, paths relative to the jjfiv/fastrank tree) and that
+ * fastrank/clib.py binds through cffi.  Semantics (ownership, JSON envelopes, error strings)
+ * follow src/ffi.rs; see INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Part 2 declares extensions (prefix `fr_`) that have no reference counterpart: device
+ * selection, restart sharding for multi-GPU runs, dense (non-JSON) result buffers, direct
+ * access to the batched line-search evaluator, and HIP-event kernel timing for bench.py.
+ *
+ * Strings: NUL-terminated UTF-8.  Every `const void*` / `const char*` JSON return value is
+ * heap-allocated by the library and must be released with free_str().  A CResult is released
+ * with free_c_result() (non-recursive: release error_message with free_str(), and the success
+ * handle later with free_dataset()/free_model()/free_cqrel()).  Exactly one of the two CResult
+ * fields is non-NULL.  Errors never use errno or exceptions: they are the JSON envelope
+ * {"error":"error","context":"<Rust Debug form of the message>"} (src/ffi.rs:22-26,45-74).
+ *
+ * All ranking arithmetic runs on the GPU; there is no CPU fallback.  Calls that need the
+ * device return an error envelope when no MI355X/HIP device is available.
+ */
+#ifndef FASTRANK_AMD_H
+#define FASTRANK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/lib.rs:50-61 -- opaque handles */
+typedef struct CDataset CDataset;
+typedef struct CModel CModel;
+typedef struct CQRel CQRel;
+
+/* src/lib.rs:63-67 */
+typedef struct CResult {
+    const void *error_message;
+    const void *success;
+} CResult;
+
+/* ---------------------------------------------------------------------------------------- */
+/* Part 1: the reference surface                                                            */
+/* ---------------------------------------------------------------------------------------- */
+
+/* src/lib.rs:78-81 */
+void free_str(void *originally_from_library);
+/* src/lib.rs:85-91 (non-recursive) */
+void free_c_result(CResult *originally_from_library);
+/* src/lib.rs:95-98 */
+void free_dataset(CDataset *originally_from_library);
+/* src/lib.rs:102-105 */
+void free_model(CModel *originally_from_library);
+/* src/lib.rs:109-112 */
+void free_cqrel(CQRel *originally_from_library);
+
+/* src/lib.rs:117-121: TREC qrel file -> CQRel */
+const CResult *load_cqrel(const void *data_path);
+/* src/lib.rs:126-131: {"qid":{"docid":gain}} -> CQRel */
+const CResult *cqrel_from_json(const void *json_str);
+/* src/lib.rs:136-142: "to_json" | "queries" | <qid> */
+const void *cqrel_query_json(const CQRel *cqrel, const void *query_str);
+
+/* src/lib.rs:147-162: ranksvm/libsvm text file (+ optional feature-name JSON) -> CDataset */
+const CResult *load_ranksvm_format(void *data_path, void *feature_names_path_or_null);
+/* src/lib.rs:167-178: JSON list of qid strings -> sampled CDataset */
+const CResult *dataset_query_sampling(CDataset *dataset, const void *queries_json_list);
+/* src/lib.rs:183-197: JSON list of feature ids -> sampled CDataset */
+const CResult *dataset_feature_sampling(CDataset *dataset, const void *feature_json_list);
+/* src/lib.rs:202-211: is_sampled | num_features | feature_ids | num_instances | queries |
+ * instances_by_query | feature_names */
+const void *dataset_query_json(void *dataset, void *json_cmd_str);
+/* src/lib.rs:216-218: coordinate_ascent_defaults | random_forest_defaults */
+const void *query_json(const void *json_cmd_str);
+
+/* src/lib.rs:224-240: borrowed row-major f32 X[n*d], f64 y[n], i64 qid[n].  The caller keeps
+ * the arrays alive for the lifetime of the dataset and of every dataset sampled from it. */
+const CResult *make_dense_dataset_f32_f64_i64(size_t n, size_t d, const float *x, const double *y,
+                                              const int64_t *qids);
+
+/* src/lib.rs:245-253: TrainRequest JSON -> CModel.  The coordinate-ascent line search runs as
+ * batched HIP launches; RandomForest training is not part of the MI355X path (error). */
+const CResult *train_model(void *train_request_json, void *dataset);
+/* src/lib.rs:258-263 */
+const CResult *model_from_json(const void *json_str);
+/* src/lib.rs:268-277: "to_json" */
+const void *model_query_json(const void *model, const void *json_cmd_str);
+
+/* src/lib.rs:283-294: {qid: metric}; qrel may be NULL */
+const void *evaluate_by_query(const CModel *model, const CDataset *dataset, const CQRel *qrel,
+                              const void *evaluator_name);
+/* src/lib.rs:299-303: {"<instance index>": score} */
+const void *predict_scores(const CModel *model, const CDataset *dataset);
+/* src/lib.rs:308-326: writes a TREC run file; JSON number of records written */
+const void *predict_to_trecrun(const CModel *model, const CDataset *dataset, const void *output_path,
+                               const void *system_name, size_t depth);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Part 2: extensions (no reference counterpart)                                            */
+/* ---------------------------------------------------------------------------------------- */
+
+/* Number of visible HIP devices (0 when none / no driver). */
+int fr_device_count(void);
+/* Select the device used by datasets created afterwards on this thread. 0 on success. */
+int fr_set_device(int ordinal);
+/* Library/ABI version string (static storage; do NOT free). */
+const char *fr_version(void);
+
+/* Restart-sharded coordinate ascent for one-process-per-GPU runs: trains restarts
+ * [restart_begin, restart_end) of the request's num_restarts (child seeds are still drawn in
+ * order from the master RNG, src/coordinate_ascent.rs:211-213) and returns JSON
+ * {"restarts":[{"restart_id":r,"score":s,"weights":[...]}...],"stats":{...}}.
+ * The caller gathers shards (RCCL all_gather) and applies fr_select_model(). */
+const void *fr_train_model_shard(const void *train_request_json, const CDataset *dataset,
+                                 uint32_t restart_begin, uint32_t restart_end);
+/* Selection rule of src/coordinate_ascent.rs:232-252 over gathered restarts.
+ * restarts_json: JSON list of {"restart_id","score","weights"}; returns a CModel. */
+const CResult *fr_select_model(const void *restarts_json, int output_ensemble);
+/* JSON stats of the most recent train_model / fr_train_model_shard call in this process:
+ * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts"}. */
+const void *fr_last_train_stats(void);
+
+/* Dense results without JSON.  out[i] = score of instance i (instances outside the dataset
+ * view are left untouched).  Returns NULL on success or an error-envelope string. */
+const void *fr_predict_scores_dense(const CModel *model, const CDataset *dataset, double *out, size_t out_len);
+/* Per-query metric in the dataset's device query order.  out_values[nq]; out_qids (optional)
+ * receives a JSON list of the qid strings in the same order via *out_qids_json (free_str). */
+const void *fr_evaluate_dense(const CModel *model, const CDataset *dataset, const CQRel *qrel,
+                              const void *evaluator_name, double *out_values, size_t out_len,
+                              const void **out_qids_json);
+/* Full per-query rank order under the reference's total order (src/evaluators.rs:34-49):
+ * out_instance_ids[n] grouped by query (device query order), best first; out_offsets[nq+1]. */
+const void *fr_rank_order(const CModel *model, const CDataset *dataset, uint32_t *out_instance_ids,
+                          size_t n, uint64_t *out_offsets, size_t nq_plus_1);
+/* Number of queries / instances in the dataset view. */
+size_t fr_dataset_num_queries(const CDataset *dataset);
+size_t fr_dataset_num_instances(const CDataset *dataset);
+
+/* The hot operator itself: batched evaluate_mean of line-search candidates
+ * (src/coordinate_ascent.rs:157-160 x src/evaluators.rs:173-184).
+ *   n_groups line groups; group g shares base weights base_weights[g*d .. g*d+d) and feature
+ *   features[g]; it has n_cand[g] (<=64) candidate values candidates[g*64 + c] for that
+ *   feature's weight.  out_means[g*64 + c] receives the mean metric.  If out_per_query is
+ *   non-NULL it receives the [nq][n_groups*64] per-query matrix.
+ * Uses the fused HIP line-search kernel for ndcg@k (k<=20) and the general sort kernel
+ * otherwise.  Returns NULL on success or an error-envelope string. */
+const void *fr_evaluate_candidates(const CDataset *dataset, const CQRel *qrel, const void *evaluator_name,
+                                   size_t n_groups, const uint32_t *features, const double *base_weights,
+                                   const uint32_t *n_cand, const double *candidates, double *out_means,
+                                   double *out_per_query);
+
+/* HIP-event timing of the library's kernels on the stream they are launched on. */
+void fr_profile_enable(int on);
+void fr_profile_reset(void);
+/* JSON list [{"kernel","launches","total_ms"}] (free_str). */
+const void *fr_profile_json(void);
+/* hipDeviceSynchronize; 0 on success. */
+int fr_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTRANK_AMD_H */
