@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- coordinate-ascent NDCG@10 evaluations/sec on an MSLR-WEB30K-shaped matrix.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  * one process per GPU (torch.distributed / RCCL when WORLD_SIZE > 1);
+  * a STEP is one lock-step coordinate-ascent tick: one fused HIP launch that evaluates every
+    line-search candidate (1 + 2*25 = 51) of every live restart on this GPU (32 restarts per
+    GPU -> 1632 reference `evaluate_mean` results per step), plus the host replay of the
+    reference's sequential accept/early-break logic;
+  * W untimed steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize();
+    time = max over ranks; value = useful evaluations of all ranks / time;
+  * weak scaling: 32 restarts per GPU (BASELINE.json configs[2] at N=1, configs[3] at N=8),
+    dataset replicated, restarts block-partitioned, one all-gather of (restart, score, weights)
+    at the end of training (not part of a step).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SHAPES = {
+    # name: (N docs, D features, Q queries, generator seed)   -- SURVEY.md section 8(d)
+    "30k": (3_800_000, 136, 31_000, 20250929),
+    "10k": (1_200_000, 136, 10_000, 20250930),
+    "tiny": (60_000, 136, 500, 20250931),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TADDS = 39.3    # 78.6 TFLOP/s FP64 vector (FMA = 2 flop) -> 39.3 T adds/s
+
+
+def gen_mslr_shaped(seed, n, d, q):
+    """Synthetic MSLR-like matrix: lognormal query lengths, 5-grade labels,
+    columns cycling uniform / small-integer (ties) / heavy-tail / sparse, label signal in 16."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(rng.lognormal(np.log(100.0), 0.6, q), 1, 1300)
+    lens = np.maximum(1, np.floor(lens * (n / lens.sum()))).astype(np.int64)
+    lens = np.minimum(lens, 1300)
+    diff = int(n - lens.sum())
+    order = rng.permutation(q)
+    i = 0
+    while diff != 0:
+        k = order[i % q]
+        if diff > 0 and lens[k] < 1300:
+            lens[k] += 1
+            diff -= 1
+        elif diff < 0 and lens[k] > 1:
+            lens[k] -= 1
+            diff += 1
+        i += 1
+    qid = np.repeat(np.arange(1, q + 1, dtype=np.int64), lens)
+    y = rng.choice(5, size=n, p=[0.515, 0.324, 0.134, 0.019, 0.008]).astype(np.float64)
+    XT = np.empty((d, n), dtype=np.float32)
+    signal = set(range(0, 128, 8)) if d >= 128 else set(range(0, d, 8))
+    for j in range(d):
+        m = j % 4
+        if m == 0:
+            col = rng.random(n)
+        elif m == 1:
+            col = np.floor(rng.exponential(2.0, n))
+        elif m == 2:
+            col = rng.lognormal(0.0, 2.0, n)
+        else:
+            col = np.where(rng.random(n) < 0.7, 0.0, rng.random(n))
+        if j in signal:
+            col = col + 0.3 * y
+        XT[j] = col.astype(np.float32)
+    X = np.ascontiguousarray(XT.T)
+    del XT
+    return X, y, qid
+
+
+def cpu_baseline(X, y, qid, params, target_seconds):
+    """Times oracle/ (the C restatement of the reference algorithm; kind="port") on the host
+    cores: threads over restarts only, like rayon in the reference.  Bounded sample."""
+    from oracle import pyoracle as o
+
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    ds = o.Dataset(X, y, qid)
+    p = dict(params)
+    p["num_restarts"] = threads
+
+    def run(max_evals):
+        t0 = time.perf_counter()
+        _, _, evals, _ = ds.ca_learn("ndcg@10", p, threads=threads, max_evals_per_restart=max_evals)
+        return int(evals.sum()), time.perf_counter() - t0
+
+    n1, t1 = run(2)
+    per_round = t1 / 2.0
+    m = int(max(2, min(200, round(target_seconds / max(per_round, 1e-6)))))
+    if m > 2:
+        n2, t2 = run(m)
+    else:
+        n2, t2 = n1, t1
+    return {
+        "value": n2 / t2,
+        "unit": "evals/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "{} restarts x {} evaluate_mean calls each of the same CA run ({} evals in {:.1f} s); "
+                  "oracle/fastrank_oracle.c, per-call query regrouping hoisted".format(threads, m, n2, t2),
+        "evals_per_s_per_core": n2 / t2 / threads,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shape", default=os.environ.get("FR_BENCH_SHAPE", "30k"), choices=sorted(SHAPES))
+    ap.add_argument("--restarts-per-gpu", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
+
+    import fastrank_amd as fr
+    from fastrank_amd import native
+
+    native.set_device(local_rank)
+    n, d, q, seed = SHAPES[args.shape]
+    t0 = time.perf_counter()
+    X, y, qid = gen_mslr_shaped(seed, n, d, q)
+    gen_s = time.perf_counter() - t0
+    dataset = fr.CDataset.from_numpy(X, y, qid)
+
+    R = args.restarts_per_gpu * world
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.num_restarts, p.num_max_iterations, p.step_base, p.step_scale = R, 25, 0.05, 2.0
+    p.tolerance, p.normalize, p.init_random, p.seed, p.quiet = 0.001, True, True, 42, True
+    begin, end = native.shard_bounds(R, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    run = native.CoordinateAscentRun(dataset, req, begin, end)  # uploads + initial evaluate_mean per restart
+    torch.cuda.synchronize()
+    upload_s = time.perf_counter() - t0
+
+    run.step(args.warmup)
+    s0 = run.state()["stats"]
+    native.profile_reset()
+    native.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    done = run.step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    native.profile_enable(False)
+    s1 = run.state()["stats"]
+    prof = native.profile_stats()
+    if done != args.steps:
+        raise SystemExit("only {} of {} steps ran (restarts converged early)".format(done, args.steps))
+
+    useful = s1["useful_evals"] - s0["useful_evals"]
+    raw = s1["raw_evals"] - s0["raw_evals"]
+    tvals = torch.tensor([elapsed, float(useful), float(raw)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tvals.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tvals.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, useful_all, raw_all = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    else:
+        elapsed_max, useful_all, raw_all = elapsed, float(useful), float(raw)
+
+    # the job's single exchange: all-gather (restart, score, weights) + deterministic selection
+    t0 = time.perf_counter()
+    st = run.state()
+    mine = st["restarts"]
+    if world > 1:
+        dim = d
+        buf = torch.zeros((args.restarts_per_gpu + 1, 3 + dim), dtype=torch.float64, device="cuda")
+        for k, r in enumerate(mine):
+            buf[k, 0], buf[k, 1], buf[k, 2] = 1.0, float(r["restart_id"]), r["score"]
+            buf[k, 3:3 + len(r["weights"])] = torch.tensor(r["weights"], dtype=torch.float64)
+        gathered = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(gathered, buf)
+        torch.cuda.synchronize()
+        allr = [{"restart_id": int(row[1]), "score": row[2], "weights": row[3:]}
+                for t in gathered for row in t.cpu().tolist() if row[0] == 1.0]
+    else:
+        allr = mine
+    allr.sort(key=lambda r: r["restart_id"])
+    best_model = native.select_model(allr, False)
+    collective_ms = (time.perf_counter() - t0) * 1e3
+    best_score = max(r["score"] for r in allr)
+
+    if rank == 0:
+        b_eval = n * (4 * d + 8)  # algorithmic bytes per evaluate_mean
+        ls = prof.get("linesearch_ndcg_kernel", {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
+        evals_per_launch = (raw / max(1, ls["launches"])) if ls["launches"] else 0.0
+        avg_s = ls["avg_ms"] * 1e-3
+        achieved = (b_eval * evals_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.shape, {}).get("linesearch_ndcg_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # true limiter of the exact batched form: f64 adds of the ordered dot product
+        adds_per_launch = n * args.restarts_per_gpu * 51 * (d - 1) / 2.0  # avg shared prefix = half the features
+        out = {
+            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape",
+            "value": useful_all / elapsed_max,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic MSLR-WEB{} shape: {} docs x {} features x {} queries, coordinate ascent "
+                            "NDCG@10, {} restarts/GPU x 25 steps/coord (configs[2])".format(
+                                args.shape.upper(), n, d, q, args.restarts_per_gpu),
+                "restarts_total": R,
+                "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
+                "evals_per_step_per_gpu": evals_per_launch,
+            },
+            "raw_evals_per_s": raw_all / elapsed_max,
+            "useful_fraction": useful_all / max(1.0, raw_all),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "linesearch_ndcg_kernel",
+                "avg_launch_ms": ls["avg_ms"],
+                "launches": ls["launches"],
+                "algorithmic_bytes_per_launch": b_eval * evals_per_launch,
+                "note": "batched: one pass over X serves every candidate of a launch, so the algorithmic "
+                        "(per-eval) bytes exceed real HBM traffic and frac can exceed 1; the true limiter is FP64 VALU",
+            },
+            "limiter": {
+                "bound": "fp64_valu_add",
+                "achieved": (adds_per_launch / avg_s / 1e12) if avg_s > 0 else 0.0,
+                "peak": FP64_VALU_PEAK_TADDS,
+                "unit": "Tadd/s",
+                "frac": (adds_per_launch / avg_s / 1e12 / FP64_VALU_PEAK_TADDS) if avg_s > 0 else 0.0,
+            },
+            "kernels_ms": {k: v["total_ms"] for k, v in prof.items()},
+            "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "final_allgather_select_ms": collective_ms,
+                      "best_score_so_far": best_score},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del run
+            out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,10 @@ def _load():
         "fr_version": (C.c_char_p, []),
         "fr_train_model_shard": (vp, [C.c_char_p, vp, C.c_uint32, C.c_uint32]),
         "fr_select_model": (res, [C.c_char_p, C.c_int]),
+        "fr_ca_begin": (vp, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "fr_ca_step": (vp, [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+        "fr_ca_state": (vp, [vp]),
+        "fr_ca_free": (None, [vp]),
         "fr_last_train_stats": (vp, []),
         "fr_predict_scores_dense": (vp, [vp, vp, vp, sz]),
         "fr_evaluate_dense": (vp, [vp, vp, vp, C.c_char_p, vp, sz, C.POINTER(vp)]),

@@ -230,15 +230,17 @@ std::string rust_display_f64(double v) {
     return out;
 }
 
-fr::Model train_ca(fr::DatasetView& view, const ParsedRequest& rq, uint32_t rbegin, uint32_t rend,
-                   std::vector<fr::RestartResult>* hist_out) {
+fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq, uint32_t rbegin,
+                   uint32_t rend, std::vector<fr::RestartResult>* hist_out) {
     auto t0 = std::chrono::steady_clock::now();
-    fr::Evaluator ev = fr::make_evaluator(view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
-    if (view.host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
-    fr::TrainStats stats;
-    std::vector<fr::RestartResult> hist = fr::ca_train(view, ev, rq.ca, rbegin, rend, &stats);
-    stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    g_last_stats = stats;
+    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+    if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+    fr::CATrainer trainer(view, std::move(ev), rq.ca, rbegin, rend);
+    while (trainer.tick()) {
+    }
+    std::vector<fr::RestartResult> hist = trainer.results();
+    trainer.stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_last_stats = trainer.stats();
     fr::Model m;
     if (hist_out) {
         *hist_out = hist;
@@ -246,6 +248,20 @@ fr::Model train_ca(fr::DatasetView& view, const ParsedRequest& rq, uint32_t rbeg
         m = fr::ca_select(hist, rq.ca.output_ensemble);
     }
     return m;
+}
+
+Value restarts_to_json(const std::vector<fr::RestartResult>& hist) {
+    Value arr = Value::array();
+    for (const auto& h : hist) {
+        Value r = Value::object();
+        r.set("restart_id", Value::uint(h.restart_id));
+        r.set("score", Value::number(h.score));
+        Value w = Value::array();
+        for (double x : h.weights) w.push(Value::number(x));
+        r.set("weights", std::move(w));
+        arr.push(std::move(r));
+    }
+    return arr;
 }
 
 }  // namespace
@@ -464,7 +480,7 @@ const CResult* train_model(void* train_request_json, void* dataset) {
         std::lock_guard<std::mutex> lk(g_api_mu);
         auto* out = new CModel();
         try {
-            out->actual = train_ca(*ds.view, rq, 0, rq.ca.num_restarts, nullptr);
+            out->actual = train_ca(ds.view, rq, 0, rq.ca.num_restarts, nullptr);
         } catch (...) {
             delete out;
             throw;
@@ -617,23 +633,69 @@ const void* fr_train_model_shard(const void* train_request_json, const CDataset*
         if (!rq.is_ca) fr::fail_str("fr_train_model_shard: only CoordinateAscent shards by restart");
         std::lock_guard<std::mutex> lk(g_api_mu);
         std::vector<fr::RestartResult> hist;
-        train_ca(*ds.view, rq, restart_begin, restart_end, &hist);
+        train_ca(ds.view, rq, restart_begin, restart_end, &hist);
         Value o = Value::object();
-        Value arr = Value::array();
-        for (const auto& h : hist) {
-            Value r = Value::object();
-            r.set("restart_id", Value::uint(h.restart_id));
-            r.set("score", Value::number(h.score));
-            Value w = Value::array();
-            for (double x : h.weights) w.push(Value::number(x));
-            r.set("weights", std::move(w));
-            arr.push(std::move(r));
-        }
-        o.set("restarts", std::move(arr));
+        o.set("restarts", restarts_to_json(hist));
         o.set("stats", stats_to_json(g_last_stats));
         return frjson::dump(o);
     });
 }
+
+struct FrTrainer {
+    std::unique_ptr<fr::CATrainer> t;
+    std::chrono::steady_clock::time_point t0;
+};
+
+void* fr_ca_begin(const void* train_request_json, const CDataset* dataset, uint32_t restart_begin,
+                  uint32_t restart_end, const void** error_out) {
+    if (error_out) *error_out = nullptr;
+    FrTrainer* h = nullptr;
+    const void* st = status_call([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
+        if (!rq.is_ca) fr::fail_str("fr_ca_begin: only CoordinateAscent");
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::Evaluator ev = fr::make_evaluator(*ds.view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+        if (ds.view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+        auto holder = std::make_unique<FrTrainer>();
+        holder->t0 = std::chrono::steady_clock::now();
+        holder->t = std::make_unique<fr::CATrainer>(ds.view, std::move(ev), rq.ca, restart_begin, restart_end);
+        h = holder.release();
+    });
+    if (st) {
+        if (error_out) *error_out = st; else free((void*)st);
+        return nullptr;
+    }
+    return h;
+}
+
+const void* fr_ca_step(void* trainer, uint64_t max_ticks, uint64_t* ticks_done, int* finished) {
+    return status_call([&]() {
+        if (!trainer) fr::fail_str("trainer pointer is null!");
+        FrTrainer* h = (FrTrainer*)trainer;
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        uint64_t n = 0;
+        bool alive = true;
+        while (n < max_ticks && (alive = h->t->tick())) n++;
+        if (ticks_done) *ticks_done = n;
+        if (finished) *finished = (!alive || h->t->done()) ? 1 : 0;
+    });
+}
+
+const void* fr_ca_state(void* trainer) {
+    return json_call([&]() {
+        if (!trainer) fr::fail_str("trainer pointer is null!");
+        FrTrainer* h = (FrTrainer*)trainer;
+        h->t->stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
+        Value o = Value::object();
+        o.set("restarts", restarts_to_json(h->t->results()));
+        o.set("stats", stats_to_json(h->t->stats()));
+        o.set("finished", Value::boolean(h->t->done()));
+        return frjson::dump(o);
+    });
+}
+
+void fr_ca_free(void* trainer) { delete (FrTrainer*)trainer; }
 
 const CResult* fr_select_model(const void* restarts_json, int output_ensemble) {
     return c_call<CModel>([&]() {

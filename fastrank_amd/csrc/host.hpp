@@ -705,21 +705,158 @@ inline void evaluate_means_generic(DatasetView& view, const Evaluator& ev, const
 // restarts advance in lock step: one device launch per "feature tick" evaluates every
 // candidate of every live restart's current line search; the host then replays the
 // reference's sequential accept / early-break logic on the returned means.
-inline std::vector<RestartResult> ca_train(DatasetView& view, const Evaluator& ev, const CAParams& p,
-                                           uint32_t rbegin, uint32_t rend, TrainStats* stats) {
-    const std::vector<uint32_t>& fids = view.features;
-    if (fids.empty()) fail_str("assertion failed: data.n_dim() > 0");
-    if (view.instances.empty()) fail_str("assertion failed: !data.instances().is_empty()");
-    frdev::DeviceDataset& dev = view.device();
-    const size_t d = dev.d();
-    uint32_t model_dim = *std::max_element(fids.begin(), fids.end()) + 1;  // :93-98
-    if (model_dim > d) fail_str("feature id out of range for this dataset");
-    rend = std::min(rend, p.num_restarts);
+class CATrainer {
+  public:
+    CATrainer(std::shared_ptr<DatasetView> view, Evaluator ev, const CAParams& p, uint32_t rbegin, uint32_t rend)
+        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features) {
+        if (fids_.empty()) fail_str("assertion failed: data.n_dim() > 0");
+        if (view_->instances.empty()) fail_str("assertion failed: !data.instances().is_empty()");
+        frdev::DeviceDataset& dev = view_->device();
+        d_ = dev.d();
+        model_dim_ = *std::max_element(fids_.begin(), fids_.end()) + 1;  // :93-98
+        if (model_dim_ > d_) fail_str("feature id out of range for this dataset");
+        rend = std::min(rend, p_.num_restarts);
 
-    Rand64 master(p.seed);
-    std::vector<uint64_t> child(p.num_restarts);
-    for (uint32_t r = 0; r < p.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
+        Rand64 master(p_.seed);
+        std::vector<uint64_t> child(p_.num_restarts);
+        for (uint32_t r = 0; r < p_.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
+        for (uint32_t r = rbegin; r < rend; r++) rs_.emplace_back(r, child[r]);
+        fused_ = frdev::DeviceDataset::linesearch_supported(ev_.measure, ev_.depth);
+        stats_.path = fused_ ? "fused_linesearch" : "generic_sort";
+        stats_.restarts = (uint32_t)rs_.size();
+        if (rs_.empty()) return;
 
+        // initial weights + initial evaluate_mean (:104-111)
+        const size_t R = rs_.size();
+        std::vector<double> w0(R * d_, 0.0);
+        for (size_t k = 0; k < R; k++) {
+            Restart& r = rs_[k];
+            r.best_w.assign(d_, 0.0);
+            if (p_.init_random) {
+                for (uint32_t f : fids_) r.best_w[f] = r.rand.rand_float() * 2.0 - 1.0;  // :50-54
+            } else {
+                for (uint32_t f : fids_) r.best_w[f] = 1.0 / (double)fids_.size();  // :60-70
+            }
+            std::copy(r.best_w.begin(), r.best_w.end(), w0.begin() + k * d_);
+        }
+        std::vector<double> means;
+        evaluate_means_generic(*view_, ev_, w0, R, means);
+        for (size_t k = 0; k < R; k++) {
+            if (means[k] != means[k]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
+            rs_[k].best_score = means[k];
+            stats_.useful_evals++;
+            stats_.raw_evals++;
+        }
+    }
+
+    bool done() const {
+        for (const Restart& r : rs_)
+            if (!r.done) return false;
+        return true;
+    }
+
+    // One lock-step tick.  Returns false when every restart had already converged.
+    bool tick() {
+        frdev::DeviceDataset& dev = view_->device();
+        groups_.clear();
+        gen_w_.clear();
+        size_t gen_B = 0;
+        bool any = false;
+        for (Restart& r : rs_) {
+            if (r.done) continue;
+            any = true;
+            if (r.pos == 0 && r.order.empty()) {
+                r.order = fids_;
+                shuffle(r.order, r.rand);  // :113-116
+                r.successes = 0;
+                if (!p_.quiet)
+                    printf("[restart %u] shuffle features and optimize (%s=%.6f)\n", r.id, ev_.name.c_str(), r.best_score);
+            }
+            uint32_t f = r.order[r.pos];
+            r.start_score = r.best_score;
+            r.base = r.best_w;
+            if (p_.normalize) l1_normalize(r.base);  // entries >= model_dim are 0 and stay 0
+            double orig = r.base[f];
+            line_candidates(orig, p_, r.cands, r.block_len);
+            if (fused_) {
+                r.first_group = groups_.size();
+                for (size_t c0 = 0; c0 < r.cands.size(); c0 += 64) {
+                    frdev::LineGroup lg;
+                    lg.feature = f;
+                    lg.weights = r.base;
+                    lg.candidates.assign(r.cands.begin() + c0, r.cands.begin() + std::min(r.cands.size(), c0 + 64));
+                    groups_.push_back(std::move(lg));
+                }
+            } else {
+                r.first_group = gen_B;
+                for (double cw : r.cands) {
+                    size_t off = gen_w_.size();
+                    gen_w_.insert(gen_w_.end(), r.base.begin(), r.base.end());
+                    gen_w_[off + f] = cw;
+                    gen_B++;
+                }
+            }
+        }
+        if (!any) return false;
+        if (fused_) {
+            std::string _err;
+            if (!dev.linesearch_ndcg(ev_.depth, ev_.norms.data(), groups_, &means_, &_err)) fail_str(_err);
+            check_flags(dev);
+        } else {
+            evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
+        }
+        stats_.ticks++;
+        stats_.groups += fused_ ? groups_.size() : gen_B;
+        for (Restart& r : rs_) {
+            if (r.done) continue;
+            uint32_t f = r.order[r.pos];
+            // replay coordinate_ascent.rs:145-176 over the batched results
+            size_t c = 0;
+            for (int s = 0; s < 3; s++) {
+                for (uint32_t it = 0; it < r.block_len[s]; it++, c++) {
+                    double sc = fused_ ? means_[(r.first_group + c / 64) * 64 + (c % 64)] : means_[r.first_group + c];
+                    stats_.useful_evals++;
+                    if (sc == sc && sc > r.best_score) {  // core.rs:57-66: NaN rejected, strict >
+                        r.best_score = sc;
+                        r.best_w = r.base;
+                        r.best_w[f] = r.cands[c];
+                        if (!p_.quiet)
+                            printf("%4u|%-16s|%9.3f|%9.3f\n", r.id, view_->core->feature_name(f).c_str(), r.cands[c], sc);
+                    }
+                }
+                if (r.best_score - r.start_score > p_.tolerance) break;  // :174
+            }
+            stats_.raw_evals += r.cands.size();
+            if (r.best_score - r.start_score > p_.tolerance) r.successes++;  // :179-182
+            r.pos++;
+            if (r.pos == r.order.size()) {
+                if (r.successes == 0) {
+                    r.done = true;  // :185
+                } else {
+                    r.pos = 0;
+                    r.order.clear();
+                }
+            }
+        }
+        return true;
+    }
+
+    std::vector<RestartResult> results() const {
+        std::vector<RestartResult> out;
+        for (const Restart& r : rs_) {
+            RestartResult rr;
+            rr.restart_id = r.id;
+            rr.score = r.best_score;
+            rr.weights.assign(r.best_w.begin(), r.best_w.begin() + model_dim_);
+            out.push_back(std::move(rr));
+        }
+        return out;
+    }
+
+    TrainStats& stats() { return stats_; }
+    const CAParams& params() const { return p_; }
+
+  private:
     struct Restart {
         uint32_t id;
         Rand64 rand;
@@ -735,141 +872,20 @@ inline std::vector<RestartResult> ca_train(DatasetView& view, const Evaluator& e
         uint32_t block_len[3] = {0, 0, 0};
         size_t first_group = 0;
         double start_score = 0.0;
-        explicit Restart(uint32_t i, uint64_t seed) : id(i), rand(seed) {}
+        Restart(uint32_t i, uint64_t seed) : id(i), rand(seed) {}
     };
-    std::vector<Restart> rs;
-    for (uint32_t r = rbegin; r < rend; r++) rs.emplace_back(r, child[r]);
-    const size_t R = rs.size();
-    const bool fused = frdev::DeviceDataset::linesearch_supported(ev.measure, ev.depth);
-    if (stats) {
-        *stats = TrainStats();
-        stats->path = fused ? "fused_linesearch" : "generic_sort";
-        stats->restarts = (uint32_t)R;
-    }
-    if (R == 0) return {};
-
-    // initial weights + initial evaluate_mean (:104-111)
-    std::vector<double> w0(R * d, 0.0);
-    for (size_t k = 0; k < R; k++) {
-        Restart& r = rs[k];
-        r.best_w.assign(d, 0.0);
-        if (p.init_random) {
-            for (uint32_t f : fids) r.best_w[f] = r.rand.rand_float() * 2.0 - 1.0;  // :50-54
-        } else {
-            for (uint32_t f : fids) r.best_w[f] = 1.0 / (double)fids.size();  // :60-70
-        }
-        std::copy(r.best_w.begin(), r.best_w.end(), w0.begin() + k * d);
-    }
-    std::vector<double> means;
-    evaluate_means_generic(view, ev, w0, R, means);
-    for (size_t k = 0; k < R; k++) {
-        if (means[k] != means[k]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
-        rs[k].best_score = means[k];
-        if (stats) {
-            stats->useful_evals++;
-            stats->raw_evals++;
-        }
-    }
-
-    std::vector<frdev::LineGroup> groups;
-    std::vector<double> gen_w;
-    for (;;) {
-        groups.clear();
-        gen_w.clear();
-        size_t gen_B = 0;
-        bool any = false;
-        for (Restart& r : rs) {
-            if (r.done) continue;
-            any = true;
-            if (r.pos == 0 && r.order.empty()) {
-                r.order = fids;
-                shuffle(r.order, r.rand);  // :113-116
-                r.successes = 0;
-                if (!p.quiet) printf("[restart %u] shuffle features and optimize (%s=%.6f)\n", r.id, ev.name.c_str(), r.best_score);
-            }
-            uint32_t f = r.order[r.pos];
-            r.start_score = r.best_score;
-            r.base = r.best_w;
-            if (p.normalize) {
-                // l1_normalize over the model's weights (length model_dim; the rest are 0)
-                l1_normalize(r.base);
-            }
-            double orig = r.base[f];
-            line_candidates(orig, p, r.cands, r.block_len);
-            if (fused) {
-                r.first_group = groups.size();
-                for (size_t c0 = 0; c0 < r.cands.size(); c0 += 64) {
-                    frdev::LineGroup lg;
-                    lg.feature = f;
-                    lg.weights = r.base;
-                    lg.candidates.assign(r.cands.begin() + c0,
-                                         r.cands.begin() + std::min(r.cands.size(), c0 + 64));
-                    groups.push_back(std::move(lg));
-                }
-            } else {
-                r.first_group = gen_B;
-                for (double cw : r.cands) {
-                    size_t off = gen_w.size();
-                    gen_w.insert(gen_w.end(), r.base.begin(), r.base.end());
-                    gen_w[off + f] = cw;
-                    gen_B++;
-                }
-            }
-        }
-        if (!any) break;
-        if (fused) {
-            std::string _err;
-            if (!dev.linesearch_ndcg(ev.depth, ev.norms.data(), groups, &means, &_err)) fail_str(_err);
-            check_flags(dev);
-        } else {
-            evaluate_means_generic(view, ev, gen_w, gen_B, means);
-        }
-        if (stats) {
-            stats->ticks++;
-            stats->groups += fused ? groups.size() : gen_B;
-        }
-        for (Restart& r : rs) {
-            if (r.done) continue;
-            uint32_t f = r.order[r.pos];
-            // replay coordinate_ascent.rs:145-176 over the batched results
-            size_t c = 0;
-            for (int s = 0; s < 3; s++) {
-                for (uint32_t it = 0; it < r.block_len[s]; it++, c++) {
-                    double sc = fused ? means[(r.first_group + c / 64) * 64 + (c % 64)] : means[r.first_group + c];
-                    if (stats) stats->useful_evals++;
-                    if (sc == sc && sc > r.best_score) {  // core.rs:57-66: NaN rejected, strict >
-                        r.best_score = sc;
-                        r.best_w = r.base;
-                        r.best_w[f] = r.cands[c];
-                        if (!p.quiet)
-                            printf("%4u|%-16s|%9.3f|%9.3f\n", r.id, view.core->feature_name(f).c_str(), r.cands[c], sc);
-                    }
-                }
-                if (r.best_score - r.start_score > p.tolerance) break;  // :174
-            }
-            if (stats) stats->raw_evals += r.cands.size();
-            if (r.best_score - r.start_score > p.tolerance) r.successes++;  // :179-182
-            r.pos++;
-            if (r.pos == r.order.size()) {
-                if (r.successes == 0) {
-                    r.done = true;  // :185
-                } else {
-                    r.pos = 0;
-                    r.order.clear();
-                }
-            }
-        }
-    }
-    std::vector<RestartResult> out;
-    for (Restart& r : rs) {
-        RestartResult rr;
-        rr.restart_id = r.id;
-        rr.score = r.best_score;
-        rr.weights.assign(r.best_w.begin(), r.best_w.begin() + model_dim);
-        out.push_back(std::move(rr));
-    }
-    return out;
-}
+    std::shared_ptr<DatasetView> view_;
+    Evaluator ev_;
+    CAParams p_;
+    std::vector<uint32_t> fids_;
+    size_t d_ = 0;
+    uint32_t model_dim_ = 0;
+    bool fused_ = false;
+    std::vector<Restart> rs_;
+    std::vector<frdev::LineGroup> groups_;
+    std::vector<double> gen_w_, means_;
+    TrainStats stats_;
+};
 
 // coordinate_ascent.rs:232-252 selection over a restart-ordered history
 inline Model ca_select(const std::vector<RestartResult>& hist, bool output_ensemble) {

@@ -120,6 +120,44 @@ def train_model_shard(dataset: CDataset, train_req, restart_begin: int, restart_
     return _json_reply(_load().fr_train_model_shard(request, dataset.pointer, restart_begin, restart_end))
 
 
+class CoordinateAscentRun:
+    """Steppable coordinate ascent on this process's GPU (fr_ca_begin / fr_ca_step / fr_ca_state).
+    One tick = one fused launch over every candidate of every live restart's line search."""
+
+    def __init__(self, dataset: CDataset, train_req, restart_begin: int = 0, restart_end: Optional[int] = None):
+        if restart_end is None:
+            restart_end = int(train_req.params.num_restarts)
+        err = C.c_void_p()
+        request = json.dumps(train_req.to_dict()).encode("utf-8")
+        self.pointer = _load().fr_ca_begin(request, dataset.pointer, restart_begin, restart_end, C.byref(err))
+        if not self.pointer:
+            _status(err.value)
+            raise RuntimeError("fr_ca_begin failed")
+        self._dataset = dataset  # keep the dataset (and its numpy buffers) alive
+        self.finished = False
+
+    def step(self, ticks: int) -> int:
+        done = C.c_uint64(0)
+        fin = C.c_int(0)
+        _status(_load().fr_ca_step(self.pointer, int(ticks), C.byref(done), C.byref(fin)))
+        self.finished = bool(fin.value)
+        return int(done.value)
+
+    def state(self) -> Dict:
+        return _json_reply(_load().fr_ca_state(self.pointer))
+
+    def close(self):
+        if self.pointer:
+            _load().fr_ca_free(self.pointer)
+            self.pointer = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def select_model(restarts: List[Dict], output_ensemble: bool = False) -> CModel:
     """src/coordinate_ascent.rs:232-252 over gathered restarts (last maximum wins ties)."""
     payload = json.dumps(restarts).encode("utf-8")

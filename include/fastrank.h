@@ -115,6 +115,17 @@ const char *fr_version(void);
  * The caller gathers shards (RCCL all_gather) and applies fr_select_model(). */
 const void *fr_train_model_shard(const void *train_request_json, const CDataset *dataset,
                                  uint32_t restart_begin, uint32_t restart_end);
+/* Steppable form of the same trainer (what bench.py times): begin -> step(k ticks)* -> state.
+ * One tick = one fused launch evaluating every line-search candidate of every live restart.
+ * fr_ca_begin returns NULL and sets *error_out (free_str) on failure. */
+void *fr_ca_begin(const void *train_request_json, const CDataset *dataset, uint32_t restart_begin,
+                  uint32_t restart_end, const void **error_out);
+/* Runs up to max_ticks ticks; NULL on success. *finished = 1 once every restart converged. */
+const void *fr_ca_step(void *trainer, uint64_t max_ticks, uint64_t *ticks_done, int *finished);
+/* JSON {"restarts":[...],"stats":{...},"finished":bool} (free_str). */
+const void *fr_ca_state(void *trainer);
+void fr_ca_free(void *trainer);
+
 /* Selection rule of src/coordinate_ascent.rs:232-252 over gathered restarts.
  * restarts_json: JSON list of {"restart_id","score","weights"}; returns a CModel. */
 const CResult *fr_select_model(const void *restarts_json, int output_ensemble);

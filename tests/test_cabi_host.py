@@ -1,0 +1,204 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/fastrank.h
+declares, speaks the reference's JSON protocol, and fails LOUDLY (no CPU fallback) when a
+compute call is made without a GPU.  No device arithmetic happens in this file."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fastrank_amd as fr
+from fastrank_amd import clib, native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "fastrank.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", text)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(clib._build.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for name in syms:
+        assert hasattr(lib, name), "missing export: " + name
+    for name in clib.exported_symbols():  # the 20 reference symbols (src/lib.rs:78-326)
+        assert name in syms
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fastrank_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "pyoracle" not in text and "liboracle" not in text and "oracle/" not in text, fn
+
+
+def test_version_and_defaults():
+    assert fr.__version__ == "0.7.0"  # tests/test_with_example_data.py:78
+    d = fr.query_json("coordinate_ascent_defaults")
+    assert d["measure"] == "ndcg" and d["judgments"] is None
+    p = d["params"]["CoordinateAscent"]
+    # src/coordinate_ascent.rs:25-41
+    assert (p["num_restarts"], p["num_max_iterations"], p["step_base"], p["step_scale"], p["tolerance"]) == (
+        5, 25, 0.05, 2.0, 0.001)
+    assert p["normalize"] is True and p["quiet"] is False and p["init_random"] is True
+    assert p["output_ensemble"] is False and 0 <= p["seed"] < 2 ** 64
+    rf = fr.query_json("random_forest_defaults")["params"]["RandomForest"]
+    assert rf["split_method"] == {"SquaredError": []} and rf["num_trees"] == 100 and rf["weight_trees"] is False
+    with pytest.raises(Exception, match="unknown_query_str: nope"):
+        fr.query_json("nope")
+
+
+def test_train_request_round_trip():
+    # tests/test_with_example_data.py:281-302 (train_req_object)
+    rust = fr.TrainRequest.from_dict(fr.query_json("coordinate_ascent_defaults"))
+    py = fr.TrainRequest()
+    for _ in range(2):
+        assert rust.measure == py.measure and rust.judgments == py.judgments
+        for k in ("num_restarts", "num_max_iterations", "step_base", "step_scale", "tolerance", "init_random",
+                  "output_ensemble", "quiet"):
+            assert getattr(rust.params, k) == getattr(py.params, k)
+        py = fr.TrainRequest.from_dict(py.to_dict())
+    big = fr.TrainRequest.coordinate_ascent()
+    big.params.seed = 2 ** 64 - 1
+    assert big.clone().params.seed == 2 ** 64 - 1
+
+
+def test_model_json_round_trip():
+    # tests/test_with_example_data.py:203-214 (wire format)
+    models = [
+        {"Linear": {"weights": [0.1, -2.5e-07, 1e21, 3.0, 0.0]}},
+        {"SingleFeature": {"fid": 3, "dir": -1.0}},
+        {"DecisionTree": {"FeatureSplit": {"fid": 1, "split": 0.5, "lhs": {"LeafNode": 1.0},
+                                           "rhs": {"FeatureSplit": {"fid": 0, "split": -2.0,
+                                                                    "lhs": {"LeafNode": 0.25}, "rhs": {"LeafNode": 7.0}}}}}},
+    ]
+    models.append({"Ensemble": {"weights": [1.0, 0.5, 2.0], "models": list(models)}})
+    for m in models:
+        cm = fr.CModel.from_dict(m)
+        assert cm.to_dict() == m
+        assert fr.CModel.from_dict(cm.to_dict()).to_dict() == m
+        assert str(cm) == str(m)
+    with pytest.raises(Exception, match="unknown variant"):
+        clib._unwrap(clib._load().model_from_json(b'{"Bogus": {}}'))
+    with pytest.raises(Exception, match="error: Error"):
+        clib._unwrap(clib._load().model_from_json(b'{"Linear": '))
+
+
+def test_serde_style_float_formatting():
+    cm = fr.CModel.from_dict({"Linear": {"weights": [1.0, 0.05, 1e-7, 1.5e300, 123456.75, 1e16, -0.0, 0.001]}})
+    raw = clib._take_str(clib._load().model_query_json(cm.pointer, b"to_json"))
+    assert raw == '{"Linear":{"weights":[1.0,0.05,1e-7,1.5e300,123456.75,1e16,-0.0,0.001]}}'
+
+
+def test_cqrel_round_trip_and_file(qrel_dict):
+    q = fr.CQRel.from_dict(qrel_dict)
+    assert q.to_dict() == qrel_dict  # tests/test_with_example_data.py:80-83
+    assert q.queries() == set(qrel_dict.keys())
+    one = sorted(qrel_dict.keys())[0]
+    assert q.query_judgments(one) == qrel_dict[one]
+    with pytest.raises(ValueError):
+        q.query_judgments("no-such-query")
+    f = fr.CQRel.load_file(os.path.join(GOLDEN, "data", "newsir18-entity.qrel"))
+    assert f.to_dict() == qrel_dict
+    with pytest.raises(Exception, match="NotFound"):
+        fr.CQRel.load_file("/nonexistent/qrel")
+
+
+def test_ranksvm_loader_introspection(known):
+    # tests/test_with_example_data.py:90-104
+    path = os.path.join(GOLDEN, "data", "trec_news_2018.train")
+    rd = fr.CDataset.open_ranksvm(path)
+    assert rd.queries() == set(known["expected_queries"])
+    assert rd.feature_ids() == set(range(known["expected_d"]))
+    assert rd.feature_names() == set(str(x) for x in range(known["expected_d"]))
+    assert rd.num_features() == known["expected_d"] and rd.num_instances() == known["expected_n"]
+    assert rd.is_sampled() is False
+    named = fr.CDataset.open_ranksvm(path, os.path.join(GOLDEN, "data", "trec_news_2018.features.json"))
+    assert named.feature_names() == set(known["feature_names"].values()) | {"0"}
+    assert named.feature_name_to_index()["pagerank"] == 4
+    with pytest.raises(Exception, match="NotFound"):
+        fr.CDataset.open_ranksvm("/nonexistent/file.train")
+
+
+def test_dense_dataset_and_sampling_views(trec, known):
+    # tests/test_with_example_data.py:216-241 (introspection half) and :106-137
+    X = trec["train_X"][:, 1:].copy()  # sklearn's zero_based=False loader drops column 0
+    train = fr.CDataset.from_numpy(X, trec["train_y"], trec["train_qid"])
+    assert train.is_sampled() is False
+    assert train.num_features() == 5 and train.num_instances() == known["expected_n"]
+    assert train.queries() == set(known["expected_queries"])
+    assert train.feature_ids() == set(range(5)) and train.feature_names() == set("01234")
+    ibq = train.instances_by_query()
+    assert sorted(sum(ibq.values(), [])) == list(range(known["expected_n"]))
+    assert all(v == sorted(v) for v in ibq.values())
+    subset = sorted(known["expected_queries"])[:10]
+    part = train.subsample_queries(subset)
+    assert part.is_sampled() is True and part.queries() == set(subset)
+    assert part.num_instances() == sum(len(ibq[q]) for q in subset)
+    assert part.num_features() == 5
+    with pytest.raises(ValueError):
+        train.subsample_queries(["not-a-query"])
+    one = train.subsample_feature_names(["3"])
+    assert one.num_features() == 1 and one.feature_ids() == {3} and one.num_instances() == known["expected_n"]
+    with pytest.raises(Exception, match=r"Missing Features: \{FeatureId\(77\)\}"):
+        clib._unwrap(clib._load().dataset_feature_sampling(train.pointer, b"[77]"))
+    with pytest.raises(Exception, match="No Features!"):
+        clib._unwrap(clib._load().dataset_feature_sampling(train.pointer, b"[]"))
+    with pytest.raises(Exception, match="unknown_dataset_query_str: wat"):
+        train._query_json("wat")
+
+
+def test_qid_out_of_u32_range_is_an_error():
+    X = np.ones((2, 1), dtype=np.float32)
+    for bad in (-1, 2 ** 32):
+        with pytest.raises(Exception, match="TryFromIntError"):
+            fr.CDataset.from_numpy(X, np.zeros(2), np.array([1, bad], dtype=np.int64))
+
+
+def test_null_handles_report_reference_messages():
+    L = clib._load()
+    assert "Dataset pointer is null!" in clib._take_str(L.dataset_query_json(None, b"queries"))
+    assert "Model pointer is null!" in clib._take_str(L.model_query_json(None, b"to_json"))
+    assert "cqrel pointer is null!" in clib._take_str(L.cqrel_query_json(None, b"queries"))
+    assert "NULL pointer: query_json_str" in clib._take_str(L.query_json(None))
+    with pytest.raises(Exception, match="Dataset pointer is null!"):
+        clib._unwrap(L.train_model(b"{}", None))
+
+
+def test_bad_measure_and_unsupported_training_are_errors(trec):
+    ds = fr.CDataset.from_numpy(trec["train_X"], trec["train_y"], trec["train_qid"])
+    m = fr.CModel.from_dict({"Linear": {"weights": [0.0] * 6}})
+    with pytest.raises(Exception, match='Invalid training measure: \\\\"p@5\\\\"'):
+        ds.evaluate(m, "p@5")
+    with pytest.raises(Exception, match="Couldn't parse after the @"):
+        ds.evaluate(m, "ndcg@x")
+    with pytest.raises(Exception, match="RandomForest training is outside"):
+        ds.train_model(fr.TrainRequest.random_forest())
+
+
+@pytest.mark.skipif(native.device_count() > 0, reason="checks the no-GPU failure mode")
+def test_compute_without_gpu_fails_loudly(trec):
+    ds = fr.CDataset.from_numpy(trec["train_X"], trec["train_y"], trec["train_qid"])
+    m = fr.CModel.from_dict({"Linear": {"weights": [1.0] * 6}})
+    for call in (lambda: ds.evaluate(m, "ndcg@5"), lambda: m.predict_scores(ds),
+                 lambda: ds.train_model(fr.TrainRequest.coordinate_ascent())):
+        with pytest.raises(Exception, match="no MI355X/HIP device"):
+            call()
+
+
+def test_shard_bounds_cover_all_restarts():
+    for R in (1, 5, 32, 256):
+        for W in (1, 2, 3, 8):
+            spans = [native.shard_bounds(R, r, W) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == R
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1

@@ -1,0 +1,421 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+reference's golden known answers.  Bit-exact for scores, rank order and per-query metrics;
+means within 1e-12 (and in practice bit-exact, since both sum sequentially in query order).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fastrank_amd as fr
+from fastrank_amd import native
+from oracle import pyoracle as o
+from tests.conftest import GOLDEN, synth_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(known):
+    names = {int(k): v for k, v in known["feature_names"].items()}
+    names[0] = "0"
+    return names
+
+
+@pytest.fixture(scope="module")
+def small():
+    X, y, qid = synth_dataset(7, 6000, 24, 60, max_len=700)
+    return X, y, qid, fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+
+
+@pytest.fixture(scope="module")
+def mslr_small():
+    """MSLR-shaped (136 features) but small enough for the CPU oracle."""
+    X, y, qid = synth_dataset(11, 30000, 136, 250)
+    return X, y, qid, fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+
+
+def _device_query_order(ds_gpu, model, measure="ndcg"):
+    qids, vals = native.evaluate_dense(model, ds_gpu, measure)
+    return qids, vals
+
+
+def test_native_library_is_loaded_and_gpu_visible():
+    assert native.device_count() >= 1
+    assert os.path.exists(fr.clib._build.LIB_PATH)
+
+
+def test_linear_scores_bit_exact(mslr_small):
+    X, y, qid, g, c = mslr_small
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        w = rng.uniform(-1, 1, X.shape[1])
+        if trial == 1:
+            w[rng.random(len(w)) < 0.5] = 0.0
+        m = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+        got = native.predict_scores_dense(m, g)
+        exp = c.score_linear(w)
+        assert np.array_equal(got, exp), "ordered unfused f64 dot product must match bit for bit"
+    # shorter weight vector: zip() stops at the shorter side (dense_dataset.rs:72)
+    m = fr.CModel.from_dict({"Linear": {"weights": [0.5, -0.25, 2.0]}})
+    assert np.array_equal(native.predict_scores_dense(m, g), c.score_linear([0.5, -0.25, 2.0]))
+    # JSON form
+    js = m.predict_scores(g)
+    assert len(js) == len(y) and js[0] == c.score_linear([0.5, -0.25, 2.0])[0]
+
+
+def test_single_feature_and_tree_models(small):
+    X, y, qid, g, c = small
+    m = fr.CModel.from_dict({"SingleFeature": {"fid": 5, "dir": -2.5}})
+    assert np.array_equal(native.predict_scores_dense(m, g), c.score_single_feature(5, -2.5))
+    rng = np.random.default_rng(5)
+
+    def rand_tree(depth):
+        if depth == 0 or rng.random() < 0.15:
+            return {"LeafNode": float(rng.uniform(0, 4))}
+        f = int(rng.integers(0, X.shape[1]))
+        return {"FeatureSplit": {"fid": f, "split": float(np.quantile(X[:, f], rng.random())),
+                                 "lhs": rand_tree(depth - 1), "rhs": rand_tree(depth - 1)}}
+
+    trees = [rand_tree(7) for _ in range(40)]
+    weights = rng.uniform(0.1, 1.0, len(trees)).tolist()
+    ens = {"Ensemble": {"weights": weights, "models": [{"DecisionTree": t} for t in trees]}}
+    got = native.predict_scores_dense(fr.CModel.from_dict(ens), g)
+    assert np.array_equal(got, c.score_ensemble(trees, weights))
+    # bare decision tree: the leaf value itself
+    got1 = native.predict_scores_dense(fr.CModel.from_dict({"DecisionTree": trees[0]}), g)
+    assert np.array_equal(got1, c.score_ensemble([trees[0]], [1.0]))
+    # mixed ensemble (coordinate ascent's output_ensemble shape): sum_t w_t * linear_t(x), unfused
+    lin = [rng.uniform(-1, 1, X.shape[1]) for _ in range(3)]
+    mixed = {"Ensemble": {"weights": [0.3, 0.5, 0.2], "models": [{"Linear": {"weights": w.tolist()}} for w in lin]}}
+    exp = np.zeros(len(y))
+    for wt, w in zip([0.3, 0.5, 0.2], lin):
+        exp = exp + wt * c.score_linear(w)
+    assert np.array_equal(native.predict_scores_dense(fr.CModel.from_dict(mixed), g), exp)
+
+
+def test_regression_tree_known_answer(known):
+    # src/random_forest.rs:465-506
+    t = known["regression_tree"]
+    X = np.asarray(t["xs"], dtype=np.float32).reshape(-1, 1)
+    y = np.asarray(t["ys"], dtype=np.float64)
+    g = fr.CDataset.from_numpy(X, y, np.zeros(len(y), dtype=np.int64))
+    tree = {"FeatureSplit": {"fid": 0, "split": 3.0, "lhs": {"LeafNode": 7.0},
+                             "rhs": {"FeatureSplit": {"fid": 0, "split": 6.0, "lhs": {"LeafNode": 2.0},
+                                                      "rhs": {"LeafNode": 12.0}}}}}
+    pred = native.predict_scores_dense(fr.CModel.from_dict({"DecisionTree": tree}), g)
+    assert np.max(np.abs(pred - y)) <= t["tolerance"]
+
+
+def test_rank_order_bit_exact_including_ties(small):
+    X, y, qid, g, c = small
+    rng = np.random.default_rng(9)
+    cases = [rng.uniform(-1, 1, X.shape[1]), np.zeros(X.shape[1])]
+    w_int = np.zeros(X.shape[1])
+    w_int[1] = 1.0  # integer-valued column: massive score ties -> gain/id tie-breaks decide
+    cases.append(w_int)
+    for w in cases:
+        m = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+        ids, offs = native.rank_order(m, g)
+        _, exp_rank, err = c.metric_from_scores("ndcg", c.score_linear(w), want_rank=True)
+        assert err == 0
+        # both sides list queries in first-appearance order
+        assert np.array_equal(offs, c.query_offsets())
+        assert np.array_equal(ids, exp_rank), "per-query rank order must be bit-exact"
+
+
+def test_rank_ties_known_answer(known):
+    # src/evaluators.rs:61-79 through the device sort
+    r = known["rank_ties"]
+    ids = np.asarray(r["ids"])
+    order = np.argsort(ids)
+    X = np.zeros((6, 1), dtype=np.float32)  # instance id = row index; ids 1..5 used
+    y = np.zeros(6)
+    for s, gn, i in zip(r["scores"], r["gains"], r["ids"]):
+        X[i, 0] = s
+        y[i] = gn
+    g = fr.CDataset.from_numpy(X[1:], y[1:], np.zeros(5, dtype=np.int64))
+    got, _ = native.rank_order(fr.CModel.from_dict({"Linear": {"weights": [1.0]}}), g)
+    assert (got + 1).tolist() == r["expected_order"]
+
+
+@pytest.mark.parametrize("measure", ["ndcg@10", "ndcg@5", "ndcg", "ndcg@1", "ndcg@20", "ndcg@1000", "map", "mrr", "AP", "RR"])
+def test_per_query_metrics_bit_exact(small, measure):
+    X, y, qid, g, c = small
+    rng = np.random.default_rng(13)
+    for w in (rng.uniform(-1, 1, X.shape[1]), np.zeros(X.shape[1])):
+        m = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+        qids, got = native.evaluate_dense(m, g, measure)
+        exp, err = c.metric_from_scores(measure, c.score_linear(w))
+        assert err == 0
+        assert qids == [str(int(q)) for q in c.query_ids()]
+        assert np.array_equal(got, exp), measure
+        by_q = g.evaluate(m, measure)
+        assert by_q == dict(zip(qids, exp.tolist()))
+
+
+def _ca_groups(rng, d, n_groups, iters=25):
+    feats, bases, cands = [], [], []
+    for _ in range(n_groups):
+        w = rng.uniform(-1, 1, d)
+        w /= np.abs(w).sum()
+        f = int(rng.integers(0, d))
+        feats.append(f)
+        bases.append(w)
+        cands.append(o.ca_candidates(w[f], 0.05, 2.0, iters))
+    return feats, np.asarray(bases), cands
+
+
+@pytest.mark.parametrize("measure", ["ndcg@10", "ndcg@5", "ndcg@20", "ndcg@3"])
+def test_fused_linesearch_matches_oracle_per_query(mslr_small, measure):
+    X, y, qid, g, c = mslr_small
+    rng = np.random.default_rng(17)
+    feats, bases, cands = _ca_groups(rng, X.shape[1], 3)
+    feats[0] = 0  # no shared prefix
+    feats[1] = X.shape[1] - 1  # everything is prefix
+    cands[0] = o.ca_candidates(bases[0][0], 0.05, 2.0, 25)
+    cands[1] = o.ca_candidates(bases[1][X.shape[1] - 1], 0.05, 2.0, 25)
+    means, pq = native.evaluate_candidates(g, measure, feats, bases, cands, per_query=True)
+    norms = c.default_norms(measure)
+    for gi in range(len(feats)):
+        for ci in (0, 1, 7, 25, 26, 50):
+            w = bases[gi].copy()
+            w[feats[gi]] = cands[gi][ci]
+            exp, err = c.metric_from_scores(measure, c.score_linear(w), norms)
+            assert err == 0
+            assert np.array_equal(pq[:, gi * 64 + ci], exp), (measure, gi, ci)
+            assert means[gi][ci] == pytest.approx(c.evaluate_mean(measure, w, norms), abs=1e-12)
+            assert means[gi][ci] == float(np.add.reduce(np.concatenate([[0.0], exp]))) / len(exp) or \
+                abs(means[gi][ci] - exp.mean()) < 1e-12
+
+
+def test_fused_and_generic_paths_agree(small):
+    """Two independent device implementations (register top-k vs LDS bitonic sort)."""
+    X, y, qid, g, c = small
+    rng = np.random.default_rng(19)
+    feats, bases, cands = _ca_groups(rng, X.shape[1], 4, iters=6)
+    fused = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands)
+    generic = native.evaluate_candidates(g, "ndcg@1000", feats, bases, cands)  # depth > 20 -> sort kernel
+    exact = native.evaluate_candidates(g, "ndcg", feats, bases, cands)
+    for gi in range(len(feats)):
+        assert np.array_equal(generic[gi], exact[gi])  # depth 1000 > every query length
+        for ci in range(len(cands[gi])):
+            w = bases[gi].copy()
+            w[feats[gi]] = cands[gi][ci]
+            assert fused[gi][ci] == c.evaluate_mean("ndcg@10", w)
+            assert exact[gi][ci] == c.evaluate_mean("ndcg", w)
+    ap = native.evaluate_candidates(g, "map", feats, bases, cands)
+    w = bases[2].copy()
+    w[feats[2]] = cands[2][3]
+    assert ap[2][3] == c.evaluate_mean("map", w)
+
+
+def test_edge_shapes_singletons_long_queries_negative_gains():
+    rng = np.random.default_rng(23)
+    lens = [1, 1, 2, 63, 64, 65, 127, 128, 129, 1300, 5, 10, 11]
+    qid = np.repeat(np.arange(100, 100 + len(lens), dtype=np.int64), lens)
+    n = len(qid)
+    perm = rng.permutation(n)  # documents of a query need not be contiguous
+    qid = qid[perm]
+    X = np.floor(rng.exponential(2.0, (n, 5))).astype(np.float32)  # many ties
+    y = rng.choice([-1.0, 0.0, 0.0, 1.0, 2.0, 4.0], size=n)
+    y[qid == 101] = 0.0  # a query with no relevant document counts as 0 in the mean
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    for w in ([1.0, 0.0, -1.0, 0.5, 0.0], [0.0] * 5):
+        m = fr.CModel.from_dict({"Linear": {"weights": w}})
+        for measure in ("ndcg@10", "ndcg", "map", "mrr"):
+            _, got = native.evaluate_dense(m, g, measure)
+            exp, _ = c.metric_from_scores(measure, c.score_linear(w))
+            assert np.array_equal(got, exp), measure
+        base = np.asarray([w], dtype=np.float64)
+        cand = [np.asarray([0.0, -0.3, 0.7, 1.5])]
+        for measure in ("ndcg@10", "ndcg@5"):
+            means, pq = native.evaluate_candidates(g, measure, [2], base, cand, per_query=True)
+            for ci, cv in enumerate(cand[0]):
+                ww = np.asarray(w, dtype=np.float64).copy()
+                ww[2] = cv
+                exp, _ = c.metric_from_scores(measure, c.score_linear(ww))
+                assert np.array_equal(pq[:, ci], exp), (measure, ci)
+                assert means[0][ci] == c.evaluate_mean(measure, ww)
+
+
+def test_golden_single_feature_ndcg5_numpy_and_ranksvm(known, trec):
+    """The reference's own end-to-end known answers (tests/test_with_example_data.py:16-23,
+    139-167): single-feature coordinate ascent, then mean NDCG@5 on the full dataset."""
+    names = _names(known)
+    rd = fr.CDataset.open_ranksvm(os.path.join(GOLDEN, "data", "trec_news_2018.train"),
+                                  os.path.join(GOLDEN, "data", "trec_news_2018.features.json"))
+    dense = fr.CDataset.from_numpy(trec["train_X"], trec["train_y"], trec["train_qid"])
+    req = fr.TrainRequest.coordinate_ascent()
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 42, True, 1, 1
+    p.step_base, p.normalize, p.init_random = 1.0, False, False
+    name_to_index = rd.feature_name_to_index()
+    for f in range(known["expected_d"]):
+        single = rd.subsample_feature_names([names[f]])
+        model = single.train_model(req)
+        got = np.mean(list(rd.evaluate(model, "ndcg@5").values()))
+        assert got == pytest.approx(known["single_feature_ndcg5"][names[f]], abs=5e-8)
+        weights = model.to_dict()["Linear"]["weights"]
+        for i, w in enumerate(weights):
+            if i != name_to_index[names[f]]:
+                assert w == 0.0
+        # same thing through the numpy/DenseDataset entry point
+        model_d = dense.subsample_feature_names([str(f)]).train_model(req)
+        got_d = np.mean(list(dense.evaluate(model_d, "ndcg@5").values()))
+        assert got_d == pytest.approx(known["single_feature_ndcg5"][names[f]], abs=5e-8)
+
+
+def test_coordinate_ascent_trajectory_matches_oracle(trec):
+    """Same seed -> same restarts, same accepted candidates, same final weights (bit-exact).
+    (Parity with the *Rust* RNG stream is unpinned; this pins device-vs-oracle.)"""
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    for measure, iters in (("ndcg@5", 25), ("ndcg@10", 5), ("map", 3), ("ndcg", 3)):
+        req = fr.TrainRequest.coordinate_ascent()
+        req.measure = measure
+        p = req.params
+        p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 42, True, 4, iters
+        shard = native.train_model_shard(g, req, 0, 4)
+        exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=4)
+        assert err == 0
+        for r in shard["restarts"]:
+            k = r["restart_id"]
+            assert r["score"] == exp_s[k], (measure, k)
+            assert r["weights"] == exp_w[k].tolist(), (measure, k)
+        assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+        model = g.train_model(req)
+        best = o.select_best(exp_s)
+        assert model.to_dict() == {"Linear": {"weights": exp_w[best].tolist()}}
+
+
+def test_coordinate_ascent_on_mslr_shape_matches_oracle(mslr_small):
+    X, y, qid, g, c = mslr_small
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 42, True, 2, 25
+    run = native.CoordinateAscentRun(g, req)
+    assert run.step(6) == 6  # six feature ticks of both restarts
+    st = run.state()
+    run.close()
+    assert st["stats"]["ticks"] == 6 and st["stats"]["path"] == "fused_linesearch"
+    assert st["stats"]["raw_evals"] == 2 + 6 * 2 * 51
+    # The oracle cannot be stopped after exactly 6 ticks, so compare through the model: the
+    # device's best-so-far weights must evaluate (on the oracle) to the device's best score.
+    for r in st["restarts"]:
+        w = np.asarray(r["weights"])
+        assert c.evaluate_mean("ndcg@10", w) == r["score"]
+
+
+def test_coordinate_ascent_full_run_wide_matrix_matches_oracle():
+    """Default hyper-parameters (25 steps, normalise, random init) to convergence on a 40-feature
+    matrix with long queries: identical restarts, scores, weights and useful-eval counts."""
+    X, y, qid = synth_dataset(31, 4000, 40, 25, max_len=400)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts = 20250929, True, 3
+    shard = native.train_model_shard(g, req, 0, 3)
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=3)
+    assert err == 0
+    for r in shard["restarts"]:
+        k = r["restart_id"]
+        assert r["score"] == exp_s[k] and r["weights"] == exp_w[k].tolist()
+    assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+    # restart sharding returns the same restarts (child seeds drawn in order from the master)
+    part = native.train_model_shard(g, req, 1, 3)
+    assert [r["restart_id"] for r in part["restarts"]] == [1, 2]
+    assert [r["score"] for r in part["restarts"]] == exp_s[1:].tolist()
+
+
+def test_ensemble_output_and_last_max_selection(trec):
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@5"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations, p.output_ensemble = 7, True, 3, 3, True
+    ens = g.train_model(req).to_dict()["Ensemble"]
+    exp_s, exp_w, _, _ = c.ca_learn("ndcg@5", p.to_dict(), threads=3)
+    assert ens["weights"] == exp_s.tolist()
+    for k, member in enumerate(ens["models"]):
+        w = exp_w[k] / np.abs(exp_w[k]).sum() if np.abs(exp_w[k]).sum() > 0 else exp_w[k]
+        assert member["Linear"]["weights"] == w.tolist()
+    tie = native.select_model([{"restart_id": 0, "score": 0.5, "weights": [1.0]},
+                               {"restart_id": 2, "score": 0.5, "weights": [3.0]},
+                               {"restart_id": 1, "score": 0.5, "weights": [2.0]}])
+    assert tie.to_dict() == {"Linear": {"weights": [3.0]}}  # Iterator::max -> last maximum
+
+
+def test_qrel_norms_and_sampled_evaluation(trec, qrel_dict):
+    # tests/test_with_example_data.py:243-269
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    qrel = fr.CQRel.from_dict(qrel_dict)
+    m = fr.CModel.from_dict({"Linear": {"weights": [0.0, 0.3, -0.2, 0.5, 0.1, 0.9]}})
+    with_q = g.evaluate(m, "ndcg@5", qrel)
+    without = g.evaluate(m, "ndcg@5")
+    assert abs(np.mean(list(with_q.values())) - np.mean(list(without.values()))) < 1e-7
+    w = np.array([0.0, 0.3, -0.2, 0.5, 0.1, 0.9])
+    for measure in ("ndcg@5", "ndcg", "map"):
+        exp, _ = c.metric_from_scores(measure, c.score_linear(w), c.qrel_norms(measure, qrel_dict))
+        got = g.evaluate(m, measure, qrel)
+        assert got == dict(zip((str(int(q)) for q in c.query_ids()), exp.tolist())), measure
+    first_ten = sorted(without.keys())[:10]
+    part = g.subsample_queries(first_ten)
+    part_scores = part.evaluate(m, "ndcg@5")
+    assert len(part_scores) == 10
+    for q in first_ten:
+        assert part_scores[q] == without[q]
+    sparse = m.predict_scores(part)
+    assert len(sparse) == part.num_instances()
+    assert len(m.predict_dense_scores(part)) >= len(sparse)
+
+
+def test_trecrun_errors_without_docids_and_nan_is_an_error(trec, tmp_path):
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g = fr.CDataset.from_numpy(X, y, qid)
+    m = fr.CModel.from_dict({"Linear": {"weights": [1.0] * 6}})
+    with pytest.raises(Exception, match="Dataset does not contain document ids"):
+        g.predict_trecrun(m, str(tmp_path / "run.txt"))  # tests/test_with_example_data.py:271-279
+    Xn = X.copy()
+    Xn[3, 2] = np.nan
+    gn = fr.CDataset.from_numpy(Xn, y, qid)
+    with pytest.raises(Exception, match="NaN"):
+        gn.evaluate(m, "ndcg@5")
+    with pytest.raises(Exception, match="NaN"):
+        native.evaluate_candidates(gn, "ndcg@5", [2], np.ones((1, 6)), [np.asarray([0.5, 1.0])])
+
+
+def test_model_serialization_keeps_map(trec):
+    # tests/test_with_example_data.py:203-214
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g = fr.CDataset.from_numpy(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.params.seed, req.params.quiet = 42, True
+    model = g.train_model(req)
+    a = g.evaluate(model, "map")
+    b = g.evaluate(fr.CModel.from_dict(model.to_dict()), "map")
+    assert a == b
+    scores = model.predict_scores(g)
+    assert 0 in scores and len(scores) - 1 in scores and len(scores) == len(y)
+    stats = native.last_train_stats()
+    assert stats["path"] == "fused_linesearch" or stats["path"] == "generic_sort"
+    assert stats["useful_evals"] <= stats["raw_evals"] and stats["ticks"] > 0
+
+
+def test_hip_event_profile_reports_hot_kernels(small):
+    X, y, qid, g, c = small
+    native.profile_reset()
+    native.profile_enable(True)
+    rng = np.random.default_rng(29)
+    feats, bases, cands = _ca_groups(rng, X.shape[1], 2, iters=25)
+    native.evaluate_candidates(g, "ndcg@10", feats, bases, cands)
+    native.profile_enable(False)
+    stats = native.profile_stats()
+    assert stats["linesearch_ndcg_kernel"]["launches"] == 1
+    assert stats["linesearch_ndcg_kernel"]["total_ms"] > 0.0
