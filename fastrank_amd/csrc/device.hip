@@ -12,7 +12,8 @@
 //                            list in registers by ordered insertion; NDCG@k per (query, candidate)
 //   metric_sort_kernel       general evaluator: LDS bitonic sort of one query's (score, position)
 //                            keys with the reference's 3-key order, then NDCG / AP / RR
-//   column_mean_kernel       mean over queries, sequential in query order (fixed summation shape)
+//   segment_sum_kernel +     mean over queries with a fixed two-level summation shape
+//   final_mean_kernel        (256-query segments summed in order, then segment partials in order)
 //   tree_ensemble_kernel     batched tree traversal, document rows staged in LDS
 #include "device.hpp"
 
@@ -20,6 +21,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -366,14 +369,44 @@ __global__ __launch_bounds__(256) void metric_sort_kernel(
     if (tid == 0) M[(size_t)q * B + b] = result;
 }
 
-// means[c] = (sum_q M[q*ldm + c]) / nq, summed sequentially in query order from 0.0
-// (src/evaluators.rs:173-184; the reference's HashMap order is unspecified, ours is fixed).
-__global__ void column_mean_kernel(const double* __restrict__ M, uint32_t ldm, uint32_t ncols, uint32_t nq,
-                                   double* __restrict__ means) {
+// Mean over queries with a FIXED two-level summation shape (the reference sums in a fresh
+// HashMap's iteration order, i.e. unspecified: src/evaluators.rs:173-184 + dense_dataset.rs:96-109):
+//   partial[s][c] = sequential sum of M[q][c] over segment s = queries [s*MEAN_SEG, (s+1)*MEAN_SEG)
+//   mean[c]       = (sequential sum of partial[s][c] over s) / nq
+// For nq <= MEAN_SEG this is the plain sequential sum in query order.
+constexpr uint32_t MEAN_SEG = 256;
+
+__global__ __launch_bounds__(64) void segment_sum_kernel(const double* __restrict__ M, uint32_t ldm, uint32_t ncols,
+                                                         uint32_t nq, double* __restrict__ partial) {
+    const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.x;
+    if (c >= ncols) return;
+    const uint32_t q0 = s * MEAN_SEG;
+    const uint32_t q1 = (q0 + MEAN_SEG < nq) ? q0 + MEAN_SEG : nq;
+    const double* p = M + (size_t)q0 * ldm + c;
+    double sum = 0.0;
+    uint32_t q = q0;
+    for (; q + 16 <= q1; q += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = p[(size_t)t * ldm];
+#pragma unroll
+        for (int t = 0; t < 16; t++) sum += v[t];
+        p += (size_t)16 * ldm;
+    }
+    for (; q < q1; q++) {
+        sum += *p;
+        p += ldm;
+    }
+    partial[(size_t)s * ldm + c] = sum;
+}
+
+__global__ void final_mean_kernel(const double* __restrict__ partial, uint32_t ldm, uint32_t ncols, uint32_t nseg,
+                                  uint32_t nq, double* __restrict__ means) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     double sum = 0.0;
-    for (uint32_t q = 0; q < nq; q++) sum += M[(size_t)q * ldm + c];
+    for (uint32_t s = 0; s < nseg; s++) sum += partial[(size_t)s * ldm + c];
     means[c] = nq ? sum / (double)nq : 0.0;
 }
 
@@ -390,17 +423,35 @@ struct LSArgs {
     const uint32_t* gncand; // [G]
     double* M;              // [nq][ldm]
     int* flags;
+    uint64_t* dbg_counters;  // [4] rows, batches, insertion rows, documents (debug bit 16)
     uint32_t ld, d, nq, G, ldm;
     int depth;
+    int debug;  // tuning knob (env FR_LS_DEBUG): 1 = skip phase K, 2 = no threshold filter, 4 = skip suffix adds, 8 = skip prefix
 };
 
 constexpr int LS_ROWPAD = 65;  // LDS row stride in doubles: 130 dwords -> 16 lanes hit 16 distinct even banks
+constexpr int LS_JB = 4;       // features per software-pipelined block of phase S
+constexpr int LS_PB = 16;      // features per load batch of the shared-prefix chain
+constexpr int LS_MAXD = 1016;  // widest matrix the fused kernel stages weights for (LDS)
 
 // The fused line search.  One wave per (query, group); CT = candidate tile (accumulators per
 // lane in phase S), K = top-K list length (>= depth), RB = documents per transpose batch.
+//
+// phase S (lane = document, 64 documents per chunk): exact ordered f64 dot products for all CT
+//   candidates at once.  The prefix sum over features < f is shared by every candidate; the
+//   products x_j*w_j for j > f are shared too, so a candidate costs one v_add_f64 per feature.
+//   Feature columns are read from the column-major matrix (256 B per wave per feature) through
+//   a register double buffer so the adds of block b hide the loads of block b+1.
+// filter: a document can only matter if it ties/beats the current K-th best score of at least
+//   one candidate; thresholds are re-published after every transpose batch.
+// phase K (lane = candidate): surviving documents are transposed through LDS in batches of RB
+//   rows and inserted, in document order, into each candidate's sorted top-K list (registers).
 template <int K, int CT, int RB>
 __global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
     __shared__ double tr[RB * LS_ROWPAD];
+    __shared__ double thr[WAVE];
+    __shared__ double wl[LS_MAXD + LS_JB];  // this group's base weights, zero padded
+    __shared__ double cwl[WAVE];            // this group's candidate weights for feature f
     const uint32_t lane = threadIdx.x;
     // XCD-aware block -> (query, group): blocks b, b+8, b+16.. run on one XCD (observed dispatch
     // b % 8), so all groups of a query share that XCD's L2 for the query's feature columns.
@@ -416,17 +467,27 @@ __global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
     const uint32_t ncand = a.gncand[g];
     const double* __restrict__ w = a.gw + (size_t)g * a.d;
     const double* __restrict__ cw = a.gcand + (size_t)g * 64;
-    const uint32_t d = a.d, ld = a.ld;
+    const uint32_t d = a.d;
+    const size_t ld = a.ld;
+    const double NEG_INF = -__builtin_huge_val();
+
+    // stage the weights in LDS: every later use is a broadcast ds_read that the compiler can
+    // issue ahead of time with counted waits (no scalar-cache round trip inside the hot loops)
+    for (uint32_t j = lane; j < d + LS_JB; j += WAVE) wl[j] = j < d ? w[j] : 0.0;
+    thr[lane] = NEG_INF;  // nothing is filtered until a candidate's list is full
+    cwl[lane] = cw[lane];
+    __syncthreads();
 
     double slot_s[K];
     uint32_t slot_p[K];
 #pragma unroll
     for (int m = 0; m < K; m++) {
-        slot_s[m] = -__builtin_huge_val();
+        slot_s[m] = NEG_INF;
         slot_p[m] = base;
     }
-    uint32_t filled = 0;
     bool nan_seen = false;
+    uint32_t dbg_rows = 0, dbg_batches = 0, dbg_ins = 0;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     for (uint32_t c0 = 0; c0 < n; c0 += WAVE) {
         // ---------------- phase S: lane = document ----------------
@@ -434,44 +495,106 @@ __global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
         const uint32_t pl = base + c0 + (lane < nchunk ? lane : nchunk - 1);
         const float* __restrict__ xp = a.xt + pl;
         double P = 0.0;  // shared prefix: features < f in order (dense_dataset.rs:71-74)
-#pragma unroll 4
-        for (uint32_t j = 0; j < f; j++) {
-            double prod = (double)xp[(size_t)j * ld] * w[j];
-            P = P + prod;
+        if (!(a.debug & 8)) {
+            // the accumulators are not live yet, so the prefix can keep two 16-feature batches of
+            // loads in flight (xa is consumed while xc is on its way)
+            float xa[LS_PB], xc[LS_PB];
+#pragma unroll
+            for (int t = 0; t < LS_PB; t++) {
+                uint32_t jj = ((uint32_t)t < f) ? (uint32_t)t : 0;
+                xa[t] = xp[(size_t)jj * ld];
+            }
+            for (uint32_t j = 0; j < f; j += LS_PB) {
+#pragma unroll
+                for (int t = 0; t < LS_PB; t++) {
+                    uint32_t jn = j + LS_PB + t;
+                    uint32_t jj = (jn < f) ? jn : 0;
+                    xc[t] = xp[(size_t)jj * ld];
+                }
+#pragma unroll
+                for (int t = 0; t < LS_PB; t++) {
+                    if (j + t < f) {
+                        double prod = (double)xa[t] * wl[j + t];
+                        P = P + prod;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < LS_PB; t++) xa[t] = xc[t];
+            }
         }
         const double xf = (double)xp[(size_t)f * ld];
+        // first block of the suffix is requested before the candidate initialisation below
+        float xb[LS_JB], xn[LS_JB];
+        uint32_t j0 = f + 1;
+#pragma unroll
+        for (int t = 0; t < LS_JB; t++) {
+            uint32_t jj = (j0 + t < d) ? j0 + t : d - 1;
+            xb[t] = xp[(size_t)jj * ld];
+        }
         double sc[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            double prod = xf * cw[c];
+            double prod = xf * cwl[c];
             sc[c] = P + prod;
         }
-#pragma unroll 2
-        for (uint32_t j = f + 1; j < d; j++) {
-            double prod = (double)xp[(size_t)j * ld] * w[j];
+        for (; j0 < d; j0 += LS_JB) {
+            const uint32_t jn = j0 + LS_JB;
 #pragma unroll
-            for (int c = 0; c < CT; c++) sc[c] = sc[c] + prod;
+            for (int t = 0; t < LS_JB; t++) {
+                uint32_t jj = (jn + t < d) ? jn + t : d - 1;
+                xn[t] = xp[(size_t)jj * ld];
+            }
+#pragma unroll
+            for (int t = 0; t < LS_JB; t++) {
+                if (j0 + t < d && !(a.debug & 4)) {
+                    double prod = (double)xb[t] * wl[j0 + t];
+#pragma unroll
+                    for (int c = 0; c < CT; c++) sc[c] = sc[c] + prod;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < LS_JB; t++) xb[t] = xn[t];
         }
-        // ---------------- transpose + phase K: lane = candidate ----------------
-        for (uint32_t b0 = 0; b0 < nchunk; b0 += RB) {
-            if (lane >= b0 && lane < b0 + RB) {
-                double* row = tr + (lane - b0) * LS_ROWPAD;
+        // ---------------- filter + transpose + phase K: lane = candidate ----------------
+        uint64_t remaining = (nchunk >= 64u) ? ~0ull : ((1ull << nchunk) - 1ull);
+        if (a.debug & 1) remaining = 0ull;
+        while (remaining != 0ull) {
+            if (!(a.debug & 2)) {
+                bool p = false;
+#pragma unroll
+                for (int c = 0; c < CT; c++) p |= (sc[c] >= thr[c]) | (sc[c] != sc[c]);
+                remaining &= __ballot(p);
+                if (remaining == 0ull) break;
+            }
+            const bool mine = (remaining >> lane) & 1ull;
+            const uint32_t myrank = __popcll(remaining & lt_mask);
+            const bool in_batch = mine && myrank < (uint32_t)RB;
+            if (in_batch) {
+                double* row = tr + myrank * LS_ROWPAD;
 #pragma unroll
                 for (int c = 0; c < CT; c++) row[c] = sc[c];
             }
+            uint64_t batch_mask = __ballot(in_batch);
+            const uint32_t nb = __popcll(batch_mask);
+            remaining &= ~batch_mask;
+            dbg_rows += nb;
+            dbg_batches++;
             __syncthreads();
-            const uint32_t nb = (nchunk - b0) < (uint32_t)RB ? (nchunk - b0) : (uint32_t)RB;
             for (uint32_t r = 0; r < nb; r++) {
-                const double e = lane < (uint32_t)CT ? tr[r * LS_ROWPAD + lane] : -__builtin_huge_val();
-                const uint32_t ep = base + c0 + b0 + r;
+                const double e = lane < (uint32_t)CT ? tr[r * LS_ROWPAD + lane] : NEG_INF;
+                // document position of the r-th set bit of the batch (rows are in lane order)
+                const uint32_t bit = (uint32_t)__ffsll((unsigned long long)batch_mask) - 1u;
+                batch_mask &= batch_mask - 1ull;
+                const uint32_t ep = base + c0 + bit;
                 nan_seen |= (e != e);
-                const bool enters = e >= slot_s[K - 1];
-                if (filled < (uint32_t)K || __ballot(enters) != 0ull) {
+                if (__ballot(e >= slot_s[K - 1]) != 0ull) {
+                    dbg_ins++;
                     // ordered insertion: e goes above every slot it ties or beats (later document
-                    // wins ties = reference tie-break in the reverse layout); empty slots lose.
+                    // wins ties = reference tie-break in the reverse layout).  Empty slots hold
+                    // -inf and therefore lose against every non-NaN score, including -inf itself.
                     bool beat[K];
 #pragma unroll
-                    for (int m = 0; m < K; m++) beat[m] = ((uint32_t)m >= filled) | (e >= slot_s[m]);
+                    for (int m = 0; m < K; m++) beat[m] = (e >= slot_s[m]);
 #pragma unroll
                     for (int m = K - 1; m >= 1; m--) {
                         slot_s[m] = beat[m - 1] ? slot_s[m - 1] : (beat[m] ? e : slot_s[m]);
@@ -479,13 +602,20 @@ __global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
                     }
                     slot_s[0] = beat[0] ? e : slot_s[0];
                     slot_p[0] = beat[0] ? ep : slot_p[0];
-                    if (filled < (uint32_t)K) filled++;
                 }
             }
+            // publish each candidate's K-th best score; unused candidate lanes never admit a document
+            thr[lane] = (lane < ncand) ? slot_s[K - 1] : __builtin_huge_val();
             __syncthreads();
         }
     }
 
+    if ((a.debug & 16) && lane == 0) {
+        atomicAdd((unsigned long long*)a.dbg_counters + 0, (unsigned long long)dbg_rows);
+        atomicAdd((unsigned long long*)a.dbg_counters + 1, (unsigned long long)dbg_batches);
+        atomicAdd((unsigned long long*)a.dbg_counters + 2, (unsigned long long)dbg_ins);
+        atomicAdd((unsigned long long*)a.dbg_counters + 3, (unsigned long long)n);
+    }
     if (lane < ncand) {
         // src/evaluators.rs:255-272,350-380
         const uint32_t L = (uint32_t)a.depth < n ? (uint32_t)a.depth : n;
@@ -504,7 +634,7 @@ __global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
             if (dcg > norm) fl |= FLAG_ACTUAL_GT_IDEAL;
             val = dcg / norm;
         }
-        if (fl) atomicOr(a.flags, fl);
+        if (fl && !a.debug) atomicOr(a.flags, fl);
         a.M[(size_t)q * a.ldm + (size_t)g * 64 + lane] = val;
     }
 }
@@ -522,8 +652,9 @@ struct DeviceDataset::Impl {
     DevBuf<double> gexp, disc;
     DevBuf<uint32_t> qoff, qorder, perm, rank;
     DevBuf<int> flags;
+    DevBuf<uint64_t> dbgc;
     // work buffers
-    DevBuf<double> scores, acc, weights, M, means, norms, gw, gcand;
+    DevBuf<double> scores, acc, weights, M, means, partial, norms, gw, gcand;
     DevBuf<uint32_t> gfeat, gncand;
     DevBuf<TreeNodeDev> nodes;
     DevBuf<int32_t> roots;
@@ -660,6 +791,25 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
         if (!chk(hipMemset(m.flags.p, 0, sizeof(int)), "clear flags")) return nullptr;
     }
     return ds;
+}
+
+static bool launch_means(DeviceDataset* self, const double* M, size_t ldm, size_t ncols, size_t nq,
+                         DevBuf<double>& partial, DevBuf<double>& means, hipStream_t st, std::string* err) {
+    (void)self;
+    const size_t nseg = (nq + MEAN_SEG - 1) / MEAN_SEG;
+    if (!partial.ensure(std::max<size_t>(1, nseg) * ldm, err) || !means.ensure(ldm, err)) return false;
+    {
+        ProfScope ps("segment_sum_kernel", st);
+        dim3 grid((unsigned)nseg, (unsigned)((ncols + 63) / 64));
+        segment_sum_kernel<<<grid, 64, 0, st>>>(M, (uint32_t)ldm, (uint32_t)ncols, (uint32_t)nq, partial.p);
+    }
+    {
+        ProfScope ps("final_mean_kernel", st);
+        final_mean_kernel<<<dim3((unsigned)((ncols + 63) / 64)), 64, 0, st>>>(partial.p, (uint32_t)ldm, (uint32_t)ncols,
+                                                                              (uint32_t)nseg, (uint32_t)nq, means.p);
+    }
+    FR_HIP(hipGetLastError());
+    return true;
 }
 
 static inline dim3 grid1d(size_t n, unsigned bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -882,13 +1032,7 @@ bool DeviceDataset::reduce_means(size_t ncols, double* out, std::string* err) {
         if (err) *err = "reduce_means: shape mismatch";
         return false;
     }
-    if (!m.means.ensure(ncols, err)) return false;
-    {
-        ProfScope ps("column_mean_kernel", m.stream);
-        column_mean_kernel<<<grid1d(ncols, 64), 64, 0, m.stream>>>(m.M.p, (uint32_t)m.last_ldm, (uint32_t)ncols,
-                                                                   (uint32_t)m.nq, m.means.p);
-    }
-    FR_HIP(hipGetLastError());
+    if (!launch_means(this, m.M.p, m.last_ldm, ncols, m.nq, m.partial, m.means, m.stream, err)) return false;
     FR_HIP(hipMemcpyAsync(out, m.means.p, ncols * sizeof(double), hipMemcpyDeviceToHost, m.stream));
     FR_HIP(hipStreamSynchronize(m.stream));
     return true;
@@ -897,6 +1041,8 @@ bool DeviceDataset::reduce_means(size_t ncols, double* out, std::string* err) {
 bool DeviceDataset::linesearch_supported(int measure, int64_t depth) {
     return measure == M_NDCG && depth >= 0 && depth <= 20;
 }
+
+size_t DeviceDataset::linesearch_max_features() { return LS_MAXD; }
 
 template <int K, int CT>
 static void launch_linesearch(const LSArgs& a, unsigned nblocks, hipStream_t st) {
@@ -917,8 +1063,8 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    if (!linesearch_supported(M_NDCG, depth)) {
-        if (err) *err = "linesearch_ndcg: unsupported depth";
+    if (!linesearch_supported(M_NDCG, depth) || m.d > (size_t)LS_MAXD) {
+        if (err) *err = "linesearch_ndcg: unsupported depth or feature count";
         return false;
     }
     const size_t G = groups.size();
@@ -949,8 +1095,6 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
     FR_HIP(hipMemcpyAsync(m.gncand.p, gncand.data(), G * sizeof(uint32_t), hipMemcpyHostToDevice, m.stream));
     FR_HIP(hipMemcpyAsync(m.gw.p, gw.data(), G * m.d * sizeof(double), hipMemcpyHostToDevice, m.stream));
     FR_HIP(hipMemcpyAsync(m.gcand.p, gcand.data(), G * 64 * sizeof(double), hipMemcpyHostToDevice, m.stream));
-    // unused candidate columns must read as 0.0 in the mean kernel
-    FR_HIP(hipMemsetAsync(m.M.p, 0, m.nq * ldm * sizeof(double), m.stream));
     LSArgs a;
     a.xt = m.xt.p;
     a.gexp = m.gexp.p;
@@ -964,12 +1108,19 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
     a.gncand = m.gncand.p;
     a.M = m.M.p;
     a.flags = m.flags.p;
+    if (!m.dbgc.ensure(4, err)) return false;
+    a.dbg_counters = m.dbgc.p;
     a.ld = (uint32_t)m.ld;
     a.d = (uint32_t)m.d;
     a.nq = (uint32_t)m.nq;
     a.G = (uint32_t)G;
     a.ldm = (uint32_t)ldm;
     a.depth = (int)depth;
+    {
+        const char* dbg = getenv("FR_LS_DEBUG");
+        a.debug = dbg ? atoi(dbg) : 0;
+        if (a.debug & 16) FR_HIP(hipMemsetAsync(m.dbgc.p, 0, 4 * sizeof(uint64_t), m.stream));
+    }
     const size_t nblocks = ((m.nq + 7) / 8) * 8 * G;
     if (nblocks > 0x7fffffffull) {
         if (err) *err = "linesearch_ndcg: grid too large";
@@ -982,15 +1133,18 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
         else dispatch_ct<20>(a, (unsigned)nblocks, maxc, m.stream);
     }
     FR_HIP(hipGetLastError());
-    {
-        ProfScope ps("column_mean_kernel", m.stream);
-        column_mean_kernel<<<grid1d(ldm, 64), 64, 0, m.stream>>>(m.M.p, (uint32_t)ldm, (uint32_t)ldm, (uint32_t)m.nq,
-                                                                 m.means.p);
-    }
-    FR_HIP(hipGetLastError());
+    if (!launch_means(this, m.M.p, ldm, ldm, m.nq, m.partial, m.means, m.stream, err)) return false;
     FR_HIP(hipMemcpyAsync(means->data(), m.means.p, ldm * sizeof(double), hipMemcpyDeviceToHost, m.stream));
     m.last_ldm = ldm;
     m.last_cols = ldm;
+    if (a.debug & 16) {
+        uint64_t c[4];
+        FR_HIP(hipMemcpyAsync(c, m.dbgc.p, sizeof(c), hipMemcpyDeviceToHost, m.stream));
+        FR_HIP(hipStreamSynchronize(m.stream));
+        fprintf(stderr, "[FR_LS_DEBUG] docs=%llu rows=%llu (%.3f of docs) batches=%llu insertion_rows=%llu\n",
+                (unsigned long long)c[3], (unsigned long long)c[0], (double)c[0] / (double)c[3], (unsigned long long)c[1],
+                (unsigned long long)c[2]);
+    }
     return m.pull_flags(err);
 }
 

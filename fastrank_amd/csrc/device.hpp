@@ -92,6 +92,7 @@ class DeviceDataset {
 
     // --- fused line search (NDCG@k, k <= 20) --------------------------------------------------
     static bool linesearch_supported(int measure, int64_t depth);
+    static size_t linesearch_max_features();
     // evaluates every candidate of every group; means[g*64 + c]
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);

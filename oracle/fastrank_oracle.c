@@ -446,14 +446,35 @@ int oracle_metric_from_scores(const oracle_dataset *ds, int measure, int64_t dep
     return err;
 }
 
-/* src/evaluators.rs:173-184: mean over all queries, sequential sum in this dataset's query
- * order; 0.0 when there are no queries. */
+/* src/evaluators.rs:173-184: mean over all queries; 0.0 when there are no queries.
+ * The reference adds the per-query values in the iteration order of a freshly built HashMap
+ * (dense_dataset.rs:96-109), i.e. in an unspecified order that changes from call to call, so
+ * only the summation SHAPE below is a choice.  Default (segment 0): one sequential pass in this
+ * dataset's query order.  oracle_set_mean_segment(S) selects the two-level shape the HIP path
+ * uses (S-query segments summed in order, then the segment partials summed in order); for
+ * nq <= S the two are identical. */
+static size_t g_mean_segment = 0;
+void oracle_set_mean_segment(size_t s) { g_mean_segment = s; }
+size_t oracle_get_mean_segment(void) { return g_mean_segment; }
+
 static double mean_seq(const double *v, size_t n) {
     if (n == 0) return 0.0;
     double sum = 0.0;
-    for (size_t i = 0; i < n; i++) sum += v[i];
+    if (g_mean_segment == 0) {
+        for (size_t i = 0; i < n; i++) sum += v[i];
+    } else {
+        for (size_t s0 = 0; s0 < n; s0 += g_mean_segment) {
+            size_t s1 = s0 + g_mean_segment < n ? s0 + g_mean_segment : n;
+            double part = 0.0;
+            for (size_t i = s0; i < s1; i++) part += v[i];
+            sum += part;
+        }
+    }
     return sum / (double)n;
 }
+
+/* exposed so tests can reduce a per-query vector with the selected shape */
+double oracle_mean(const double *v, size_t n) { return mean_seq(v, n); }
 
 typedef struct {
     double *scores; /* [n] */

@@ -74,6 +74,10 @@ def lib():
     L.oracle_select_best.argtypes = [vp, u32, u32]
     L.oracle_ca_candidates.restype = sz
     L.oracle_ca_candidates.argtypes = [dbl, dbl, dbl, u32, vp]
+    L.oracle_set_mean_segment.argtypes = [sz]
+    L.oracle_get_mean_segment.restype = sz
+    L.oracle_mean.restype = dbl
+    L.oracle_mean.argtypes = [vp, sz]
     L.oracle_rand64_stream.argtypes = [u64, sz, vp]
     L.oracle_shuffle_with_seed.argtypes = [u64, vp, sz]
     _lib = L
@@ -247,6 +251,19 @@ class Dataset:
         err = lib().oracle_ca_learn(self.ptr, C.byref(p), kind, depth, _p(norms), _p(fids), len(fids),
                                     threads, b, e, _p(scores), _p(weights), _p(evals))
         return scores, weights, evals, err
+
+
+DEVICE_MEAN_SEGMENT = 256  # fastrank_amd/csrc/device.hip MEAN_SEG
+
+
+def set_mean_segment(seg: int) -> None:
+    """0 = one sequential pass (default); 256 = the HIP path's two-level summation shape."""
+    lib().oracle_set_mean_segment(int(seg))
+
+
+def mean(values) -> float:
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    return lib().oracle_mean(_p(values), len(values))
 
 
 def rank_order(scores, gains, ids):

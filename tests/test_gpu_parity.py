@@ -419,3 +419,38 @@ def test_hip_event_profile_reports_hot_kernels(small):
     stats = native.profile_stats()
     assert stats["linesearch_ndcg_kernel"]["launches"] == 1
     assert stats["linesearch_ndcg_kernel"]["total_ms"] > 0.0
+
+
+def test_mean_summation_shape_many_queries():
+    """More than 256 queries: the device sums 256-query segments, then the segment partials
+    (device.hip MEAN_SEG).  Bit-exact against the oracle run with the same shape; within 1e-12 of
+    the plain sequential sum (the reference's own order is unspecified)."""
+    X, y, qid = synth_dataset(37, 9000, 12, 900, max_len=60)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    rng = np.random.default_rng(41)
+    feats, bases, cands = _ca_groups(rng, X.shape[1], 2, iters=4)
+    fused = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands)
+    generic = native.evaluate_candidates(g, "map", feats, bases, cands)
+    try:
+        for gi in range(2):
+            for ci in range(len(cands[gi])):
+                w = bases[gi].copy()
+                w[feats[gi]] = cands[gi][ci]
+                o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+                assert fused[gi][ci] == c.evaluate_mean("ndcg@10", w)
+                assert generic[gi][ci] == c.evaluate_mean("map", w)
+                o.set_mean_segment(0)
+                assert abs(fused[gi][ci] - c.evaluate_mean("ndcg@10", w)) < 1e-12
+        # trajectories stay identical when both sides use the same summation shape
+        o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+        req = fr.TrainRequest.coordinate_ascent()
+        req.measure = "ndcg@10"
+        p = req.params
+        p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 5, True, 2, 6
+        shard = native.train_model_shard(g, req, 0, 2)
+        exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+        for r in shard["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+        assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+    finally:
+        o.set_mean_segment(0)
