@@ -171,35 +171,28 @@ def shard_bounds(num_restarts: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def train_model_distributed(dataset: CDataset, train_req, group=None) -> CModel:
-    """One process per GPU: every rank holds a replica of the dataset, trains its block of random
-    restarts, then ONE all-gather of (restart_id, score, weights) over RCCL/xGMI (gloo on CPU test
-    rigs) and the same deterministic selection on every rank."""
+def gather_restarts(mine: List[Dict], num_restarts: int, group=None) -> List[Dict]:
+    """The job's single exchange: one all_gather of fixed-size (valid, restart_id, score, weights)
+    records over RCCL/xGMI (backend "nccl") or gloo (CPU test rigs).  Returns every rank's
+    restarts in restart order, identically on every rank."""
     import torch
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized():
-        return dataset.train_model(train_req)
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    R = int(train_req.params.num_restarts)
-    begin, end = shard_bounds(R, rank, world)
-    shard = train_model_shard(dataset, train_req, begin, end)
-    mine = shard["restarts"]
-    dim = max((len(r["weights"]) for r in mine), default=0)
-    dim_t = torch.tensor([dim], dtype=torch.int64)
+        return sorted(mine, key=lambda r: r["restart_id"])
+    world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    dim_t = dim_t.to(dev)
+    dim_t = torch.tensor([max((len(r["weights"]) for r in mine), default=0)], dtype=torch.int64, device=dev)
     dist.all_reduce(dim_t, op=dist.ReduceOp.MAX, group=group)
     dim = int(dim_t.item())
-    per_rank = (R + world - 1) // world
-    # fixed-size record per restart slot: [valid, restart_id, score, w_0..w_dim-1]
+    per_rank = (num_restarts + world - 1) // world
     buf = torch.zeros((per_rank, 3 + dim), dtype=torch.float64)
     for k, r in enumerate(mine):
         buf[k, 0] = 1.0
         buf[k, 1] = float(r["restart_id"])
         buf[k, 2] = r["score"]
-        buf[k, 3 : 3 + len(r["weights"])] = torch.tensor(r["weights"], dtype=torch.float64)
+        buf[k, 3:3 + len(r["weights"])] = torch.tensor(r["weights"], dtype=torch.float64)
     buf = buf.to(dev)
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf, group=group)
@@ -209,6 +202,22 @@ def train_model_distributed(dataset: CDataset, train_req, group=None) -> CModel:
             if row[0] == 1.0:
                 restarts.append({"restart_id": int(row[1]), "score": row[2], "weights": row[3:]})
     restarts.sort(key=lambda r: r["restart_id"])
+    return restarts
+
+
+def train_model_distributed(dataset: CDataset, train_req, group=None) -> CModel:
+    """One process per GPU: every rank holds a replica of the dataset, trains its block of random
+    restarts, then ONE all-gather (gather_restarts) and the same deterministic selection on every
+    rank.  No data-path collective."""
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        return dataset.train_model(train_req)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    R = int(train_req.params.num_restarts)
+    begin, end = shard_bounds(R, rank, world)
+    shard = train_model_shard(dataset, train_req, begin, end)
+    restarts = gather_restarts(shard["restarts"], R, group)
     model = select_model(restarts, bool(train_req.params.output_ensemble))
     model.params = train_req
     return model
