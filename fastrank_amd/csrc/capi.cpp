@@ -812,8 +812,7 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
         for (size_t g = 0; g < n_groups; g++)
             if (n_cand[g] == 0 || n_cand[g] > 64 || features[g] >= d)
                 fr::fail_str("fr_evaluate_candidates: malformed group");
-        if (frdev::DeviceDataset::linesearch_supported(ev.measure, ev.depth) &&
-            d <= frdev::DeviceDataset::linesearch_max_features()) {
+        if (dev.linesearch_supported(ev.measure, ev.depth)) {
             std::vector<frdev::LineGroup> groups(n_groups);
             for (size_t g = 0; g < n_groups; g++) {
                 groups[g].feature = features[g];

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 namespace frdev {
 
@@ -156,39 +157,55 @@ struct DevBuf {
 constexpr int WAVE = 64;
 constexpr uint32_t IDX_INVALID = 0xFFFFFFFFu;
 
-// scores[b*ld + p] = sum_j f64(x[p][j]) * w[b][j], j ascending, unfused (dense_dataset.rs:67-76)
+// Blocked feature layout ("tiles"): documents live in a padded position space p; tile = p >> 6
+// holds 64 documents; inside a tile features are grouped by four:
+//     float index(p, j) = ((p >> 6) * dq + (j >> 2)) * 256 + (p & 63) * 4 + (j & 3),  dq = ceil(D / 4)
+// so lane = document reads 16 B (four consecutive features) per load and a wave reads 1 KiB
+// contiguous.  Feature columns D..4*dq-1 and padding documents are zero.
+__host__ __device__ inline size_t xb_index(uint32_t p, uint32_t j, uint32_t dq) {
+    return ((size_t)(p >> 6) * dq + (j >> 2)) * 256 + (size_t)(p & 63) * 4 + (j & 3);
+}
+
+// scores[b*np + p] = sum_j f64(x[p][j]) * w[b][j], j ascending, unfused (dense_dataset.rs:67-76).
+// Weights arrive zero-padded to 4*dq: a padded column contributes x*0 = +0.0, which never changes
+// the running sum (the sum starts at +0.0 and can therefore never be -0.0).
 template <int BT>
-__global__ __launch_bounds__(256) void score_linear_kernel(const float* __restrict__ xt, uint32_t ld,
-                                                           uint32_t n, uint32_t d,
+__global__ __launch_bounds__(256) void score_linear_kernel(const float4* __restrict__ xb, uint32_t np, uint32_t dq,
                                                            const double* __restrict__ w, uint32_t B,
                                                            double* __restrict__ scores) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b0 = blockIdx.y * BT;
-    if (p >= n) return;
+    if (p >= np) return;
     double acc[BT];
 #pragma unroll
     for (int t = 0; t < BT; t++) acc[t] = 0.0;
-    const float* xp = xt + p;
-#pragma unroll 4
-    for (uint32_t j = 0; j < d; j++) {
-        double x = (double)xp[(size_t)j * ld];
+    const float4* xp = xb + (size_t)(p >> 6) * dq * 64 + (p & 63);
+    const uint32_t dp = dq * 4;
+#pragma unroll 2
+    for (uint32_t j4 = 0; j4 < dq; j4++) {
+        float4 x4 = xp[(size_t)j4 * 64];
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-        for (int t = 0; t < BT; t++) {
-            uint32_t b = b0 + t < B ? b0 + t : B - 1;
-            double prod = x * w[(size_t)b * d + j];
-            acc[t] = acc[t] + prod;
+        for (int u = 0; u < 4; u++) {
+            double x = (double)xs[u];
+#pragma unroll
+            for (int t = 0; t < BT; t++) {
+                uint32_t b = b0 + t < B ? b0 + t : B - 1;
+                double prod = x * w[(size_t)b * dp + j4 * 4 + u];
+                acc[t] = acc[t] + prod;
+            }
         }
     }
 #pragma unroll
     for (int t = 0; t < BT; t++)
-        if (b0 + t < B) scores[(size_t)(b0 + t) * ld + p] = acc[t];
+        if (b0 + t < B) scores[(size_t)(b0 + t) * np + p] = acc[t];
 }
 
 // SingleFeatureModel (src/model.rs:35-40): dir * f64(x[fid])
-__global__ void score_single_feature_kernel(const float* __restrict__ xt, uint32_t ld, uint32_t n,
-                                            uint32_t fid, double dir, double* __restrict__ scores) {
+__global__ void score_single_feature_kernel(const float* __restrict__ xb, uint32_t np, uint32_t dq, uint32_t fid,
+                                            double dir, double* __restrict__ scores) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) scores[p] = dir * (double)xt[(size_t)fid * ld + p];
+    if (p < np) scores[p] = dir * (double)xb[xb_index(p, fid, dq)];
 }
 
 __global__ void fill_kernel(double* __restrict__ a, uint32_t n, double v) {
@@ -215,23 +232,29 @@ struct TreeNodeDev {
 
 // Batched tree-ensemble scoring (src/model.rs:64-84,104-112; config 5 of BASELINE.json).
 // One thread = one document.  With ROWS_IN_LDS the block first stages its documents' feature
-// rows from the column-major matrix into LDS (coalesced 256-B column segments in, row stride
-// d+1 dwords so lane-strided accesses spread over the banks), then every tree walk reads
-// features from LDS; node records come from L1/L2 (all lanes walk the same tree).
+// rows from the tiles into LDS (16-byte loads in, row stride d+1 dwords so lane-strided accesses
+// spread over the banks), then every tree walk reads features from LDS; node records come from
+// L1/L2 (all lanes walk the same tree).
 template <bool ROWS_IN_LDS>
-__global__ __launch_bounds__(128) void tree_ensemble_kernel(const float* __restrict__ xt, uint32_t ld,
-                                                            uint32_t n, uint32_t d,
-                                                            const TreeNodeDev* __restrict__ nodes,
+__global__ __launch_bounds__(128) void tree_ensemble_kernel(const float* __restrict__ xb, uint32_t np, uint32_t dq,
+                                                            uint32_t d, const TreeNodeDev* __restrict__ nodes,
                                                             const int32_t* __restrict__ roots,
                                                             const double* __restrict__ tw, uint32_t ntrees,
                                                             int raw_single, double* __restrict__ scores) {
-    extern __shared__ float rows[];  // [blockDim.x][d+1]
+    extern __shared__ float rows[];  // [blockDim.x][4*dq+1]
     const uint32_t tid = threadIdx.x;
-    const uint32_t p = blockIdx.x * blockDim.x + tid;
-    const uint32_t pc = p < n ? p : n - 1;
-    const uint32_t rs = d + 1;
+    const uint32_t p = blockIdx.x * blockDim.x + tid;  // np is a multiple of 64 and of the block size
+    const uint32_t rs = dq * 4 + 1;
     if (ROWS_IN_LDS) {
-        for (uint32_t j = 0; j < d; j++) rows[tid * rs + j] = xt[(size_t)j * ld + pc];
+        const float4* xp = (const float4*)xb + (size_t)(p >> 6) * dq * 64 + (p & 63);
+        for (uint32_t j4 = 0; j4 < dq; j4++) {
+            float4 v = xp[(size_t)j4 * 64];
+            float* r = rows + tid * rs + j4 * 4;
+            r[0] = v.x;
+            r[1] = v.y;
+            r[2] = v.z;
+            r[3] = v.w;
+        }
         __syncthreads();
     }
     double acc = 0.0;
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(128) void tree_ensemble_kernel(const float* __restr
         while (nd.fid >= 0) {
             float xv;
             if ((uint32_t)nd.fid < d) {
-                xv = ROWS_IN_LDS ? rows[tid * rs + (uint32_t)nd.fid] : xt[(size_t)nd.fid * ld + pc];
+                xv = ROWS_IN_LDS ? rows[tid * rs + (uint32_t)nd.fid] : xb[xb_index(p, (uint32_t)nd.fid, dq)];
             } else {
                 xv = 0.0f;  // Features::get -> None -> unwrap_or(0.0) (src/model.rs:72-73)
             }
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(128) void tree_ensemble_kernel(const float* __restr
             acc = acc + prod;
         }
     }
-    if (p < n) scores[p] = acc;
+    if (p < np) scores[p] = acc;
 }
 
 // a precedes b in the reference order?  Positions are in reverse tie-break layout, so among equal
@@ -271,19 +294,19 @@ __device__ __forceinline__ bool key_before(double sa, uint32_t ia, double sb, ui
 // General evaluator for one (query, score slot): LDS bitonic sort + metric.
 // dynamic LDS: double keys[npad]; uint32 idx[npad]; (npad = pow2 >= longest query)
 __global__ __launch_bounds__(256) void metric_sort_kernel(
-    const double* __restrict__ scores, uint32_t ld, const uint32_t* __restrict__ qoff,
-    const double* __restrict__ gexp, const float* __restrict__ gain, const double* __restrict__ disc,
-    const double* __restrict__ norms, int measure, int depth, uint32_t B, double* __restrict__ M,
-    uint32_t* __restrict__ rank_out, const uint32_t* __restrict__ perm, int* __restrict__ flags,
-    uint32_t npad_max) {
+    const double* __restrict__ scores, uint32_t np, const uint32_t* __restrict__ qstart,
+    const uint32_t* __restrict__ qlen, const uint32_t* __restrict__ qtight, const double* __restrict__ gexp,
+    const float* __restrict__ gain, const double* __restrict__ disc, const double* __restrict__ norms, int measure,
+    int depth, uint32_t B, double* __restrict__ M, uint32_t* __restrict__ rank_out, const uint32_t* __restrict__ perm,
+    int* __restrict__ flags, uint32_t npad_max) {
     extern __shared__ double lds_raw[];
     double* keys = lds_raw;
     uint32_t* idx = (uint32_t*)(keys + npad_max);
     const uint32_t q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t base = qoff[q], n = qoff[q + 1] - base;
+    const uint32_t base = qstart[q], n = qlen[q];
     uint32_t npad = 1;
     while (npad < n) npad <<= 1;
-    const double* sc = scores + (size_t)b * ld + base;
+    const double* sc = scores + (size_t)b * np + base;
     bool nan_seen = false;
     for (uint32_t i = tid; i < npad; i += nt) {
         if (i < n) {
@@ -317,8 +340,10 @@ __global__ __launch_bounds__(256) void metric_sort_kernel(
             __syncthreads();
         }
     }
-    if (rank_out != nullptr && b == 0)
-        for (uint32_t i = tid; i < n; i += nt) rank_out[base + i] = perm[base + idx[i]];
+    if (rank_out != nullptr && b == 0) {
+        const uint32_t tb = qtight[q];
+        for (uint32_t i = tid; i < n; i += nt) rank_out[tb + i] = perm[base + idx[i]];
+    }
     double result = 0.0;
     if (measure == M_NDCG) {
         // src/evaluators.rs:255-272,350-380: terms in rank order, sequential sum from 0.0
@@ -411,231 +436,263 @@ __global__ void final_mean_kernel(const double* __restrict__ partial, uint32_t l
 }
 
 struct LSArgs {
-    const float* xt;
-    const double* gexp;
-    const uint32_t* qoff;
-    const uint32_t* qorder;
+    const float4* xb;         // feature tiles
+    const uint32_t* gcls;     // [np] gain class of each document
+    const double* dcgtab;     // [ncls][LS_KT]: (2^gain - 1) / log2(i + 2), divided on the host
+    const uint32_t* qstart;   // [nq] padded start position
+    const uint32_t* qlen;     // [nq]
+    const uint32_t* run_q0;   // [nruns] first query of the run
+    const uint32_t* run_q1;   // [nruns] one past its last query
+    const uint32_t* run_pos;  // [nruns] first position (multiple of 64)
+    const uint32_t* run_docs; // [nruns] documents in the run
+    const uint32_t* run_order;// [nruns] longest-first schedule
     const double* norms;
     const double* disc;
-    const uint32_t* gfeat;  // [G]
-    const double* gw;       // [G][d]
-    const double* gcand;    // [G][64]
-    const uint32_t* gncand; // [G]
-    double* M;              // [nq][ldm]
+    const uint32_t* gfeat;    // [G]
+    const double* gw;         // [G][4*dq] zero padded
+    const double* gcand;      // [G][64]
+    const uint32_t* gncand;   // [G]
+    double* M;                // [nq][ldm]
     int* flags;
-    uint64_t* dbg_counters;  // [4] rows, batches, insertion rows, documents (debug bit 16)
-    uint32_t ld, d, nq, G, ldm;
+    unsigned long long* dbg_counters;  // [4] rows, batches, insertion rows, documents (debug bit 16)
+    uint32_t dq, d, nruns, G, ldm;
     int depth;
-    int debug;  // tuning knob (env FR_LS_DEBUG): 1 = skip phase K, 2 = no threshold filter, 4 = skip suffix adds, 8 = skip prefix
+    int debug;  // tuning knob (env FR_LS_DEBUG): 1 = skip phase K, 2 = no threshold filter, 16 = count rows
 };
 
 constexpr int LS_ROWPAD = 65;  // LDS row stride in doubles: 130 dwords -> 16 lanes hit 16 distinct even banks
-constexpr int LS_JB = 4;       // features per software-pipelined block of phase S
-constexpr int LS_PB = 16;      // features per load batch of the shared-prefix chain
-constexpr int LS_MAXD = 1016;  // widest matrix the fused kernel stages weights for (LDS)
+constexpr int LS_KT = 20;      // ranks covered by the per-gain-class DCG term table
+#ifndef LS_WAVES_PER_SIMD
+#define LS_WAVES_PER_SIMD 3
+#endif
 
-// The fused line search.  One wave per (query, group); CT = candidate tile (accumulators per
-// lane in phase S), K = top-K list length (>= depth), RB = documents per transpose batch.
+__device__ __forceinline__ uint64_t lane_range_mask(uint32_t lo, uint32_t hi) {
+    const uint64_t up = (hi >= 64u) ? ~0ull : ((1ull << hi) - 1ull);
+    return up & ~((1ull << lo) - 1ull);
+}
+
+// The fused line search.  One wave per (run of consecutive queries, line group); CT = candidate
+// tile (accumulators per lane in phase S), K = top-K list length (>= depth), RB = documents per
+// transpose batch.
 //
-// phase S (lane = document, 64 documents per chunk): exact ordered f64 dot products for all CT
-//   candidates at once.  The prefix sum over features < f is shared by every candidate; the
-//   products x_j*w_j for j > f are shared too, so a candidate costs one v_add_f64 per feature.
-//   Feature columns are read from the column-major matrix (256 B per wave per feature) through
-//   a register double buffer so the adds of block b hide the loads of block b+1.
-// filter: a document can only matter if it ties/beats the current K-th best score of at least
-//   one candidate; thresholds are re-published after every transpose batch.
-// phase K (lane = candidate): surviving documents are transposed through LDS in batches of RB
-//   rows and inserted, in document order, into each candidate's sorted top-K list (registers).
+// phase S (lane = document, one 64-document tile per step; tiles are full because a run packs
+//   several queries): exact ordered f64 dot products for all CT candidates at once.  The prefix
+//   sum over features < f is shared by every candidate and so are the products x_j*w_j (j > f):
+//   a candidate costs one v_add_f64 per feature.  Features arrive four at a time (16-byte loads,
+//   prefetched two groups ahead); weights come from LDS where two masked copies (w_j for j < f,
+//   w_j for j > f, zero elsewhere) remove every per-feature branch: a masked product is +-0.0 and
+//   adding it changes nothing, because a sum that starts at +0.0 can never be -0.0.
+// filter: a document can only matter if it ties/beats the current K-th best score of at least one
+//   candidate; thresholds are re-published after every transpose batch.
+// phase K (lane = candidate): surviving documents of the current query are transposed through LDS
+//   in batches of RB rows and inserted, in document order, into each candidate's sorted top-K
+//   list (registers).  At a query boundary inside the tile the lists are turned into NDCG@k.
 template <int K, int CT, int RB>
-__global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
+__global__ __launch_bounds__(WAVE, LS_WAVES_PER_SIMD) void linesearch_ndcg_kernel(LSArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double wdyn[];  // wpre[4*dq], wsuf[4*dq]
     __shared__ double tr[RB * LS_ROWPAD];
     __shared__ double thr[WAVE];
-    __shared__ double wl[LS_MAXD + LS_JB];  // this group's base weights, zero padded
-    __shared__ double cwl[WAVE];            // this group's candidate weights for feature f
+    __shared__ double cwl[WAVE];  // this group's candidate weights for feature f
+    __shared__ uint32_t rowcls[RB];
     const uint32_t lane = threadIdx.x;
-    // XCD-aware block -> (query, group): blocks b, b+8, b+16.. run on one XCD (observed dispatch
-    // b % 8), so all groups of a query share that XCD's L2 for the query's feature columns.
+    // XCD-aware block -> (run, group): blocks b, b+8, b+16.. run on one XCD (observed dispatch
+    // b % 8), so all groups of a run share that XCD's L2 for the run's feature tiles.
     const uint32_t blk = blockIdx.x;
     const uint32_t xcd = blk & 7u, seq = blk >> 3;
     const uint32_t g = seq % a.G;
-    const uint32_t qi = (seq / a.G) * 8u + xcd;
-    if (qi >= a.nq) return;
-    const uint32_t q = a.qorder[qi];
-    const uint32_t base = a.qoff[q];
-    const uint32_t n = a.qoff[q + 1] - base;
+    const uint32_t ri = (seq / a.G) * 8u + xcd;
+    if (ri >= a.nruns) return;
+    const uint32_t r = a.run_order[ri];
+    uint32_t q = a.run_q0[r];
+    const uint32_t q1 = a.run_q1[r];
+    const uint32_t pos = a.run_pos[r];
+    const uint32_t run_end = pos + a.run_docs[r];
     const uint32_t f = a.gfeat[g];
     const uint32_t ncand = a.gncand[g];
-    const double* __restrict__ w = a.gw + (size_t)g * a.d;
-    const double* __restrict__ cw = a.gcand + (size_t)g * 64;
-    const uint32_t d = a.d;
-    const size_t ld = a.ld;
+    const uint32_t dq = a.dq, dp = a.dq * 4, d = a.d;
+    const double* __restrict__ w = a.gw + (size_t)g * dp;
     const double NEG_INF = -__builtin_huge_val();
-
-    // stage the weights in LDS: every later use is a broadcast ds_read that the compiler can
-    // issue ahead of time with counted waits (no scalar-cache round trip inside the hot loops)
-    for (uint32_t j = lane; j < d + LS_JB; j += WAVE) wl[j] = j < d ? w[j] : 0.0;
+    double* wpre = wdyn;
+    double* wsuf = wdyn + dp;
+    for (uint32_t j = lane; j < dp; j += WAVE) {
+        const double wv = j < d ? w[j] : 0.0;
+        wpre[j] = j < f ? wv : 0.0;
+        wsuf[j] = j > f ? wv : 0.0;
+    }
     thr[lane] = NEG_INF;  // nothing is filtered until a candidate's list is full
-    cwl[lane] = cw[lane];
+    cwl[lane] = a.gcand[(size_t)g * 64 + lane];
     __syncthreads();
 
     double slot_s[K];
-    uint32_t slot_p[K];
+    uint32_t slot_c[K];  // gain class of the document in each slot
 #pragma unroll
     for (int m = 0; m < K; m++) {
         slot_s[m] = NEG_INF;
-        slot_p[m] = base;
+        slot_c[m] = 0;
     }
     bool nan_seen = false;
     uint32_t dbg_rows = 0, dbg_batches = 0, dbg_ins = 0;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t qn = a.qlen[q];
+    uint32_t q_end = pos + qn;  // one past the current query's last position
+    const uint32_t ngp = (f + 3) >> 2;   // tile groups that hold prefix features
+    const uint32_t sq0 = (f + 1) >> 2;   // first tile group that holds a suffix feature
+    const uint32_t fgrp = f >> 2, fsub = f & 3;
 
-    for (uint32_t c0 = 0; c0 < n; c0 += WAVE) {
+    for (uint32_t pb = pos; pb < run_end; pb += WAVE) {
         // ---------------- phase S: lane = document ----------------
-        const uint32_t nchunk = (n - c0) < (uint32_t)WAVE ? (n - c0) : (uint32_t)WAVE;
-        const uint32_t pl = base + c0 + (lane < nchunk ? lane : nchunk - 1);
-        const float* __restrict__ xp = a.xt + pl;
+        const float4* __restrict__ tile = a.xb + (size_t)(pb >> 6) * dq * 64 + lane;
+        const uint32_t mycls = a.gcls[pb + lane];
         double P = 0.0;  // shared prefix: features < f in order (dense_dataset.rs:71-74)
-        if (!(a.debug & 8)) {
-            // the accumulators are not live yet, so the prefix can keep two 16-feature batches of
-            // loads in flight (xa is consumed while xc is on its way)
-            float xa[LS_PB], xc[LS_PB];
+        if (ngp > 0) {
+            float4 xa[4], xc[4];
 #pragma unroll
-            for (int t = 0; t < LS_PB; t++) {
-                uint32_t jj = ((uint32_t)t < f) ? (uint32_t)t : 0;
-                xa[t] = xp[(size_t)jj * ld];
-            }
-            for (uint32_t j = 0; j < f; j += LS_PB) {
+            for (int u = 0; u < 4; u++) xa[u] = tile[(size_t)((uint32_t)u < ngp ? (uint32_t)u : ngp - 1) * 64];
+            for (uint32_t j4 = 0; j4 < ngp; j4 += 4) {
 #pragma unroll
-                for (int t = 0; t < LS_PB; t++) {
-                    uint32_t jn = j + LS_PB + t;
-                    uint32_t jj = (jn < f) ? jn : 0;
-                    xc[t] = xp[(size_t)jj * ld];
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t jn = j4 + 4 + u;
+                    xc[u] = tile[(size_t)(jn < ngp ? jn : ngp - 1) * 64];
                 }
 #pragma unroll
-                for (int t = 0; t < LS_PB; t++) {
-                    if (j + t < f) {
-                        double prod = (double)xa[t] * wl[j + t];
-                        P = P + prod;
+                for (int u = 0; u < 4; u++) {
+                    if (j4 + u < ngp) {
+                        const double* wp = wpre + (j4 + u) * 4;
+                        double p0 = (double)xa[u].x * wp[0];
+                        P = P + p0;
+                        double p1 = (double)xa[u].y * wp[1];
+                        P = P + p1;
+                        double p2 = (double)xa[u].z * wp[2];
+                        P = P + p2;
+                        double p3 = (double)xa[u].w * wp[3];
+                        P = P + p3;
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < LS_PB; t++) xa[t] = xc[t];
+                for (int u = 0; u < 4; u++) xa[u] = xc[u];
             }
         }
-        const double xf = (double)xp[(size_t)f * ld];
-        // first block of the suffix is requested before the candidate initialisation below
-        float xb[LS_JB], xn[LS_JB];
-        uint32_t j0 = f + 1;
-#pragma unroll
-        for (int t = 0; t < LS_JB; t++) {
-            uint32_t jj = (j0 + t < d) ? j0 + t : d - 1;
-            xb[t] = xp[(size_t)jj * ld];
-        }
+        const double xf = (double)((const float*)(tile + (size_t)fgrp * 64))[fsub];
+        // two tile groups of the suffix are requested before the candidate initialisation
+        float4 x0 = tile[(size_t)(sq0 < dq ? sq0 : dq - 1) * 64];
+        float4 x1 = tile[(size_t)(sq0 + 1 < dq ? sq0 + 1 : dq - 1) * 64];
         double sc[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
             double prod = xf * cwl[c];
             sc[c] = P + prod;
         }
-        for (; j0 < d; j0 += LS_JB) {
-            const uint32_t jn = j0 + LS_JB;
+        for (uint32_t j4 = sq0; j4 < dq; j4++) {
+            const float4 x2 = tile[(size_t)(j4 + 2 < dq ? j4 + 2 : dq - 1) * 64];
+            const double* wp = wsuf + j4 * 4;
+            const float xs[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
-            for (int t = 0; t < LS_JB; t++) {
-                uint32_t jj = (jn + t < d) ? jn + t : d - 1;
-                xn[t] = xp[(size_t)jj * ld];
+            for (int u = 0; u < 4; u++) {
+                double prod = (double)xs[u] * wp[u];
+#pragma unroll
+                for (int c = 0; c < CT; c++) sc[c] = sc[c] + prod;
             }
-#pragma unroll
-            for (int t = 0; t < LS_JB; t++) {
-                if (j0 + t < d && !(a.debug & 4)) {
-                    double prod = (double)xb[t] * wl[j0 + t];
-#pragma unroll
-                    for (int c = 0; c < CT; c++) sc[c] = sc[c] + prod;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < LS_JB; t++) xb[t] = xn[t];
+            x0 = x1;
+            x1 = x2;
         }
         // ---------------- filter + transpose + phase K: lane = candidate ----------------
-        uint64_t remaining = (nchunk >= 64u) ? ~0ull : ((1ull << nchunk) - 1ull);
-        if (a.debug & 1) remaining = 0ull;
-        while (remaining != 0ull) {
-            if (!(a.debug & 2)) {
-                bool p = false;
+        const uint32_t nvalid = (run_end - pb) < (uint32_t)WAVE ? (run_end - pb) : (uint32_t)WAVE;
+        uint32_t lo = 0;
+        while (lo < nvalid) {
+            const uint32_t seg_hi = (q_end - pb) < nvalid ? (q_end - pb) : nvalid;
+            uint64_t remaining = lane_range_mask(lo, seg_hi);
+            if (a.debug & 1) remaining = 0ull;
+            while (remaining != 0ull) {
+                if (!(a.debug & 2)) {
+                    bool p = false;
 #pragma unroll
-                for (int c = 0; c < CT; c++) p |= (sc[c] >= thr[c]) | (sc[c] != sc[c]);
-                remaining &= __ballot(p);
-                if (remaining == 0ull) break;
-            }
-            const bool mine = (remaining >> lane) & 1ull;
-            const uint32_t myrank = __popcll(remaining & lt_mask);
-            const bool in_batch = mine && myrank < (uint32_t)RB;
-            if (in_batch) {
-                double* row = tr + myrank * LS_ROWPAD;
-#pragma unroll
-                for (int c = 0; c < CT; c++) row[c] = sc[c];
-            }
-            uint64_t batch_mask = __ballot(in_batch);
-            const uint32_t nb = __popcll(batch_mask);
-            remaining &= ~batch_mask;
-            dbg_rows += nb;
-            dbg_batches++;
-            __syncthreads();
-            for (uint32_t r = 0; r < nb; r++) {
-                const double e = lane < (uint32_t)CT ? tr[r * LS_ROWPAD + lane] : NEG_INF;
-                // document position of the r-th set bit of the batch (rows are in lane order)
-                const uint32_t bit = (uint32_t)__ffsll((unsigned long long)batch_mask) - 1u;
-                batch_mask &= batch_mask - 1ull;
-                const uint32_t ep = base + c0 + bit;
-                nan_seen |= (e != e);
-                if (__ballot(e >= slot_s[K - 1]) != 0ull) {
-                    dbg_ins++;
-                    // ordered insertion: e goes above every slot it ties or beats (later document
-                    // wins ties = reference tie-break in the reverse layout).  Empty slots hold
-                    // -inf and therefore lose against every non-NaN score, including -inf itself.
-                    bool beat[K];
-#pragma unroll
-                    for (int m = 0; m < K; m++) beat[m] = (e >= slot_s[m]);
-#pragma unroll
-                    for (int m = K - 1; m >= 1; m--) {
-                        slot_s[m] = beat[m - 1] ? slot_s[m - 1] : (beat[m] ? e : slot_s[m]);
-                        slot_p[m] = beat[m - 1] ? slot_p[m - 1] : (beat[m] ? ep : slot_p[m]);
-                    }
-                    slot_s[0] = beat[0] ? e : slot_s[0];
-                    slot_p[0] = beat[0] ? ep : slot_p[0];
+                    for (int c = 0; c < CT; c++) p |= (sc[c] >= thr[c]) | (sc[c] != sc[c]);
+                    remaining &= __ballot(p);
+                    if (remaining == 0ull) break;
                 }
+                const bool mine = (remaining >> lane) & 1ull;
+                const uint32_t myrank = __popcll(remaining & lt_mask);
+                const bool in_batch = mine && myrank < (uint32_t)RB;
+                if (in_batch) {
+                    double* row = tr + myrank * LS_ROWPAD;
+#pragma unroll
+                    for (int c = 0; c < CT; c++) row[c] = sc[c];
+                    rowcls[myrank] = mycls;
+                }
+                const uint64_t batch_mask = __ballot(in_batch);
+                const uint32_t nb = __popcll(batch_mask);
+                remaining &= ~batch_mask;
+                dbg_rows += nb;
+                dbg_batches++;
+                __syncthreads();
+                for (uint32_t rr = 0; rr < nb; rr++) {
+                    const double e = lane < (uint32_t)CT ? tr[rr * LS_ROWPAD + lane] : NEG_INF;
+                    const uint32_t ep = rowcls[rr];
+                    nan_seen |= (e != e);
+                    if (__ballot(e >= slot_s[K - 1]) != 0ull) {
+                        dbg_ins++;
+                        // ordered insertion: e goes above every slot it ties or beats (later document
+                        // wins ties = reference tie-break in the reverse layout).  Empty slots hold
+                        // -inf and therefore lose against every non-NaN score, including -inf itself.
+                        bool beat[K];
+#pragma unroll
+                        for (int m = 0; m < K; m++) beat[m] = (e >= slot_s[m]);
+#pragma unroll
+                        for (int m = K - 1; m >= 1; m--) {
+                            slot_s[m] = beat[m - 1] ? slot_s[m - 1] : (beat[m] ? e : slot_s[m]);
+                            slot_c[m] = beat[m - 1] ? slot_c[m - 1] : (beat[m] ? ep : slot_c[m]);
+                        }
+                        slot_s[0] = beat[0] ? e : slot_s[0];
+                        slot_c[0] = beat[0] ? ep : slot_c[0];
+                    }
+                }
+                // publish each candidate's K-th best score; unused candidate lanes never admit a document
+                thr[lane] = (lane < ncand) ? slot_s[K - 1] : __builtin_huge_val();
+                __syncthreads();
             }
-            // publish each candidate's K-th best score; unused candidate lanes never admit a document
-            thr[lane] = (lane < ncand) ? slot_s[K - 1] : __builtin_huge_val();
+            if (q_end - pb > (uint32_t)WAVE) break;  // the query continues in the next tile
+            // ---- the current query is complete: NDCG@k (src/evaluators.rs:255-272,350-380) ----
+            if (lane < ncand) {
+                const uint32_t L = (uint32_t)a.depth < qn ? (uint32_t)a.depth : qn;
+                double dcg = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    if ((uint32_t)i < L) {
+                        double term = a.dcgtab[(size_t)slot_c[i] * LS_KT + i];
+                        dcg = dcg + term;
+                    }
+                }
+                const double norm = a.norms[q];
+                double val = 0.0;
+                int fl = 0;
+                if (norm == norm) {
+                    if (dcg > norm) fl |= FLAG_ACTUAL_GT_IDEAL;
+                    val = dcg / norm;
+                }
+                if (fl && !a.debug) atomicOr(a.flags, fl);
+                a.M[(size_t)q * a.ldm + (size_t)g * 64 + lane] = val;
+            }
+            lo = seg_hi;
+            q++;
+            if (q >= q1) break;
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                slot_s[m] = NEG_INF;
+                slot_c[m] = 0;
+            }
+            qn = a.qlen[q];
+            q_end += qn;
+            __syncthreads();  // every lane has read thr[] for the finished query
+            thr[lane] = NEG_INF;
             __syncthreads();
         }
     }
-
+    if (nan_seen && !a.debug) atomicOr(a.flags, FLAG_NAN_SCORE);
     if ((a.debug & 16) && lane == 0) {
-        atomicAdd((unsigned long long*)a.dbg_counters + 0, (unsigned long long)dbg_rows);
-        atomicAdd((unsigned long long*)a.dbg_counters + 1, (unsigned long long)dbg_batches);
-        atomicAdd((unsigned long long*)a.dbg_counters + 2, (unsigned long long)dbg_ins);
-        atomicAdd((unsigned long long*)a.dbg_counters + 3, (unsigned long long)n);
-    }
-    if (lane < ncand) {
-        // src/evaluators.rs:255-272,350-380
-        const uint32_t L = (uint32_t)a.depth < n ? (uint32_t)a.depth : n;
-        double dcg = 0.0;
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            if ((uint32_t)i < L) {
-                double term = a.gexp[slot_p[i]] / a.disc[i];
-                dcg = dcg + term;
-            }
-        }
-        const double norm = a.norms[q];
-        double val = 0.0;
-        int fl = nan_seen ? FLAG_NAN_SCORE : 0;
-        if (norm == norm) {
-            if (dcg > norm) fl |= FLAG_ACTUAL_GT_IDEAL;
-            val = dcg / norm;
-        }
-        if (fl && !a.debug) atomicOr(a.flags, fl);
-        a.M[(size_t)q * a.ldm + (size_t)g * 64 + lane] = val;
+        atomicAdd(a.dbg_counters + 0, (unsigned long long)dbg_rows);
+        atomicAdd(a.dbg_counters + 1, (unsigned long long)dbg_batches);
+        atomicAdd(a.dbg_counters + 2, (unsigned long long)dbg_ins);
+        atomicAdd(a.dbg_counters + 3, (unsigned long long)(run_end - pos));
     }
 }
 
@@ -646,13 +703,15 @@ __global__ __launch_bounds__(WAVE) void linesearch_ndcg_kernel(LSArgs a) {
 struct DeviceDataset::Impl {
     int device = 0;
     hipStream_t stream = nullptr;
-    size_t n = 0, d = 0, nq = 0, ld = 0, maxlen = 0;
-    std::vector<uint32_t> perm_host;
-    DevBuf<float> xt, gain;
+    size_t n = 0, d = 0, nq = 0, np = 0, dq = 0, maxlen = 0, nruns = 0;
+    bool nonfinite = false;            // X holds inf/NaN: zero-weight masking is not exact -> no fused path
+    std::vector<uint32_t> perm_host;   // [np] original instance id or IDX_INVALID (padding)
+    DevBuf<float> xb, gain;
     DevBuf<double> gexp, disc;
-    DevBuf<uint32_t> qoff, qorder, perm, rank;
+    DevBuf<uint32_t> qstart, qlen, qtight, perm, rank, run_q0, run_q1, run_pos, run_docs, run_order, gcls;
+    DevBuf<double> dcgtab;
     DevBuf<int> flags;
-    DevBuf<uint64_t> dbgc;
+    DevBuf<unsigned long long> dbgc;
     // work buffers
     DevBuf<double> scores, acc, weights, M, means, partial, norms, gw, gcand;
     DevBuf<uint32_t> gfeat, gncand;
@@ -699,8 +758,8 @@ size_t DeviceDataset::max_query_len() const { return impl_->maxlen; }
 size_t DeviceDataset::last_ldm() const { return impl_->last_ldm; }
 size_t DeviceDataset::hbm_bytes() const {
     const Impl& m = *impl_;
-    return m.xt.bytes() + m.gain.bytes() + m.gexp.bytes() + m.disc.bytes() + m.qoff.bytes() +
-           m.qorder.bytes() + m.perm.bytes();
+    return m.xb.bytes() + m.gain.bytes() + m.gexp.bytes() + m.disc.bytes() + m.qstart.bytes() + m.qlen.bytes() +
+           m.qtight.bytes() + m.perm.bytes();
 }
 
 int DeviceDataset::take_flags() {
@@ -708,6 +767,13 @@ int DeviceDataset::take_flags() {
     int v = impl_->host_flags;
     impl_->host_flags = 0;
     return v;
+}
+
+template <typename T>
+static bool upload(DevBuf<T>& buf, const std::vector<T>& host, std::string* err) {
+    if (!buf.ensure(std::max<size_t>(host.size(), 1), err)) return false;
+    if (!host.empty()) FR_HIP(hipMemcpy(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return true;
 }
 
 std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::string* err) {
@@ -720,7 +786,7 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
         return fail("no MI355X/HIP device available for the fastrank_amd compute path (" +
                     (e2.empty() ? std::string("device count is 0") : e2) + ")");
     if (csr.n == 0 || csr.d == 0 || csr.nq == 0) return fail("empty dataset");
-    if (csr.n >= 0xFFFFFF00ull) return fail("dataset too large for 32-bit instance ids");
+    if (csr.n >= 0xF0000000ull) return fail("dataset too large for 32-bit document positions");
     std::shared_ptr<DeviceDataset> ds(new DeviceDataset());
     Impl& m = *ds->impl_;
     if (hipGetDevice(&m.device) != hipSuccess) return fail("hipGetDevice failed");
@@ -733,69 +799,144 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
     m.n = csr.n;
     m.d = csr.d;
     m.nq = csr.nq;
-    m.ld = (csr.n + 63) / 64 * 64;
-    m.perm_host = csr.perm;
-    for (size_t q = 0; q < csr.nq; q++) m.maxlen = std::max<size_t>(m.maxlen, csr.qoff[q + 1] - csr.qoff[q]);
+    m.dq = (csr.d + 3) / 4;
 
-    if (!m.xt.ensure(m.d * m.ld, err) || !m.gain.ensure(m.n, err) || !m.gexp.ensure(m.n, err) ||
-        !m.qoff.ensure(m.nq + 1, err) || !m.qorder.ensure(m.nq, err) || !m.perm.ensure(m.n, err) ||
-        !m.flags.ensure(1, err))
-        return nullptr;
-    // Host-side transpose in column panels, uploaded panel by panel (one-time cost; SURVEY 8d
-    // excludes it from evals/s, bench.py reports it separately).
+    // ---- runs: consecutive queries packed into whole 64-document tiles ----------------------
+    size_t target = 768;
+    if (const char* t = getenv("FR_RUN_DOCS")) target = std::max<size_t>(64, (size_t)atoll(t));
+    std::vector<uint32_t> qstart(m.nq), qlen(m.nq), qtight(m.nq + 1), run_q0, run_q1, run_pos, run_docs;
     {
-        const size_t PANEL = 8;
-        std::vector<float> panel(PANEL * m.ld, 0.0f);
-        for (size_t j0 = 0; j0 < m.d; j0 += PANEL) {
-            size_t jn = std::min(PANEL, m.d - j0);
-            for (size_t p = 0; p < m.n; p++) {
-                const float* row = csr.x + (size_t)csr.perm[p] * csr.d + j0;
-                for (size_t jj = 0; jj < jn; jj++) panel[jj * m.ld + p] = row[jj];
-            }
-            if (!chk(hipMemcpy(m.xt.p + j0 * m.ld, panel.data(), jn * m.ld * sizeof(float),
-                               hipMemcpyHostToDevice),
-                     "upload X panel"))
-                return nullptr;
+        size_t pos = 0, cur_docs = 0;
+        uint32_t cur_q0 = 0;
+        auto close_run = [&](uint32_t q_end) {
+            run_q0.push_back(cur_q0);
+            run_q1.push_back(q_end);
+            run_pos.push_back((uint32_t)(pos - cur_docs));
+            run_docs.push_back((uint32_t)cur_docs);
+            pos = (pos + 63) / 64 * 64;
+            cur_docs = 0;
+            cur_q0 = q_end;
+        };
+        for (size_t q = 0; q < m.nq; q++) {
+            size_t len = csr.qoff[q + 1] - csr.qoff[q];
+            m.maxlen = std::max(m.maxlen, len);
+            if (cur_docs > 0 && cur_docs + len > target) close_run((uint32_t)q);
+            qstart[q] = (uint32_t)pos;
+            qlen[q] = (uint32_t)len;
+            qtight[q] = csr.qoff[q];
+            pos += len;
+            cur_docs += len;
+        }
+        if (cur_docs > 0) close_run((uint32_t)m.nq);
+        qtight[m.nq] = csr.qoff[m.nq];
+        m.np = pos;
+        if (m.np >= 0xFFFFFF00ull) return fail("dataset too large for 32-bit document positions");
+    }
+    m.nruns = run_q0.size();
+    std::vector<uint32_t> run_order(m.nruns);
+    for (size_t r = 0; r < m.nruns; r++) run_order[r] = (uint32_t)r;
+    // longest-first schedule so the biggest runs do not form the tail of a launch
+    std::stable_sort(run_order.begin(), run_order.end(), [&](uint32_t x, uint32_t y) { return run_docs[x] > run_docs[y]; });
+
+    // ---- padded per-position arrays ------------------------------------------------------------
+    m.perm_host.assign(m.np, IDX_INVALID);
+    std::vector<float> gain(m.np, 0.0f);
+    std::vector<double> gexp(m.np, 0.0);
+    for (size_t q = 0; q < m.nq; q++) {
+        for (uint32_t k = 0; k < qlen[q]; k++) {
+            size_t p = (size_t)qstart[q] + k, t = (size_t)csr.qoff[q] + k;
+            m.perm_host[p] = csr.perm[t];
+            gain[p] = csr.gain[t];
+            // (2^g - 1) with the platform libm, exactly like 2.0_f64.powf(gain) - 1.0
+            // (src/evaluators.rs:266-270); g is the f32 gain widened to f64.
+            gexp[p] = std::pow(2.0, (double)csr.gain[t]) - 1.0;
         }
     }
+
+    // ---- gain classes and the per-class DCG term table: term(c, i) = (2^g_c - 1) / log2(i + 2), the
+    // exact expression of src/evaluators.rs:266-270 evaluated once per (class, rank) on the host
+    std::vector<uint32_t> gcls(m.np, 0);
+    std::vector<double> dcgtab;
     {
-        std::vector<double> gexp(m.n);
-        // (2^g - 1) with the platform libm, exactly like 2.0_f64.powf(gain) - 1.0
-        // (src/evaluators.rs:266-270); g is the f32 gain widened to f64.
-        for (size_t p = 0; p < m.n; p++) gexp[p] = std::pow(2.0, (double)csr.gain[p]) - 1.0;
-        if (!chk(hipMemcpy(m.gexp.p, gexp.data(), m.n * sizeof(double), hipMemcpyHostToDevice), "upload gexp"))
-            return nullptr;
-        if (!chk(hipMemcpy(m.gain.p, csr.gain.data(), m.n * sizeof(float), hipMemcpyHostToDevice), "upload gain"))
-            return nullptr;
+        std::map<uint32_t, uint32_t> cls_of_bits;
+        std::vector<float> cls_gain;
+        for (size_t p = 0; p < m.np; p++) {
+            if (m.perm_host[p] == IDX_INVALID) continue;
+            float gv = gain[p] == 0.0f ? 0.0f : gain[p];  // -0.0 and +0.0 are one class
+            uint32_t bits;
+            std::memcpy(&bits, &gv, sizeof(bits));
+            auto it = cls_of_bits.find(bits);
+            if (it == cls_of_bits.end()) {
+                it = cls_of_bits.emplace(bits, (uint32_t)cls_gain.size()).first;
+                cls_gain.push_back(gv);
+            }
+            gcls[p] = it->second;
+        }
+        if (cls_gain.empty()) cls_gain.push_back(0.0f);
+        dcgtab.resize(cls_gain.size() * LS_KT);
+        for (size_t c = 0; c < cls_gain.size(); c++)
+            for (int i = 0; i < LS_KT; i++)
+                dcgtab[c * LS_KT + i] = (std::pow(2.0, (double)cls_gain[c]) - 1.0) / std::log2((double)i + 2.0);
+    }
+
+    // ---- feature tiles: built on the host in slabs (threads over tiles), uploaded slab by slab.
+    // One-time cost; SURVEY 8d excludes it from evals/s and bench.py reports it separately.
+    const size_t ntiles = m.np / 64;
+    const size_t tile_floats = m.dq * 256;
+    if (!m.xb.ensure(ntiles * tile_floats, err)) return nullptr;
+    {
+        const size_t slab_tiles = std::max<size_t>(1, (size_t(256) << 20) / (tile_floats * sizeof(float)));
+        std::vector<float> slab(std::min(slab_tiles, ntiles) * tile_floats);
+        unsigned hw = std::thread::hardware_concurrency();
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, 32));
+        std::vector<char> bad(nthreads, 0);
+        for (size_t t0 = 0; t0 < ntiles; t0 += slab_tiles) {
+            const size_t tn = std::min(slab_tiles, ntiles - t0);
+            std::fill(slab.begin(), slab.begin() + tn * tile_floats, 0.0f);
+            auto work = [&](size_t tid) {
+                for (size_t t = t0 + tid; t < t0 + tn; t += nthreads) {
+                    float* tile = slab.data() + (t - t0) * tile_floats;
+                    for (size_t l = 0; l < 64; l++) {
+                        uint32_t id = m.perm_host[t * 64 + l];
+                        if (id == IDX_INVALID) continue;
+                        const float* row = csr.x + (size_t)id * csr.d;
+                        for (size_t j = 0; j < csr.d; j++) {
+                            float v = row[j];
+                            if (!std::isfinite(v)) bad[tid] = 1;
+                            tile[(j >> 2) * 256 + l * 4 + (j & 3)] = v;
+                        }
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t tid = 1; tid < nthreads; tid++) pool.emplace_back(work, tid);
+            work(0);
+            for (auto& th : pool) th.join();
+            if (!chk(hipMemcpy(m.xb.p + t0 * tile_floats, slab.data(), tn * tile_floats * sizeof(float),
+                               hipMemcpyHostToDevice),
+                     "upload feature tiles"))
+                return nullptr;
+        }
+        for (char b : bad) m.nonfinite = m.nonfinite || b;
+    }
+    {
         size_t nd = std::max<size_t>(m.maxlen, 64);
         std::vector<double> disc(nd);
         for (size_t i = 0; i < nd; i++) disc[i] = std::log2((double)i + 2.0);
-        if (!m.disc.ensure(nd, err)) return nullptr;
-        if (!chk(hipMemcpy(m.disc.p, disc.data(), nd * sizeof(double), hipMemcpyHostToDevice), "upload disc"))
+        if (!upload(m.disc, disc, err) || !upload(m.gexp, gexp, err) || !upload(m.gain, gain, err) ||
+            !upload(m.qstart, qstart, err) || !upload(m.qlen, qlen, err) || !upload(m.qtight, qtight, err) ||
+            !upload(m.perm, m.perm_host, err) || !upload(m.run_q0, run_q0, err) || !upload(m.run_q1, run_q1, err) ||
+            !upload(m.run_pos, run_pos, err) || !upload(m.run_docs, run_docs, err) ||
+            !upload(m.run_order, run_order, err) || !upload(m.gcls, gcls, err) || !upload(m.dcgtab, dcgtab, err))
             return nullptr;
-        if (!chk(hipMemcpy(m.qoff.p, csr.qoff.data(), (m.nq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice),
-                 "upload qoff"))
-            return nullptr;
-        if (!chk(hipMemcpy(m.perm.p, csr.perm.data(), m.n * sizeof(uint32_t), hipMemcpyHostToDevice),
-                 "upload perm"))
-            return nullptr;
-        // longest-first schedule so the 1k-document queries do not form the tail of a launch
-        std::vector<uint32_t> order(m.nq);
-        for (size_t q = 0; q < m.nq; q++) order[q] = (uint32_t)q;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            return (csr.qoff[x + 1] - csr.qoff[x]) > (csr.qoff[y + 1] - csr.qoff[y]);
-        });
-        if (!chk(hipMemcpy(m.qorder.p, order.data(), m.nq * sizeof(uint32_t), hipMemcpyHostToDevice),
-                 "upload qorder"))
-            return nullptr;
+        if (!m.flags.ensure(1, err) || !m.dbgc.ensure(4, err)) return nullptr;
         if (!chk(hipMemset(m.flags.p, 0, sizeof(int)), "clear flags")) return nullptr;
     }
     return ds;
 }
 
-static bool launch_means(DeviceDataset* self, const double* M, size_t ldm, size_t ncols, size_t nq,
-                         DevBuf<double>& partial, DevBuf<double>& means, hipStream_t st, std::string* err) {
-    (void)self;
+static bool launch_means(const double* M, size_t ldm, size_t ncols, size_t nq, DevBuf<double>& partial,
+                         DevBuf<double>& means, hipStream_t st, std::string* err) {
     const size_t nseg = (nq + MEAN_SEG - 1) / MEAN_SEG;
     if (!partial.ensure(std::max<size_t>(1, nseg) * ldm, err) || !means.ensure(ldm, err)) return false;
     {
@@ -819,20 +960,23 @@ bool DeviceDataset::score_linear(size_t B, const double* weights, std::string* e
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
     if (B == 0) return true;
-    if (!m.scores.ensure(B * m.ld, err) || !m.weights.ensure(B * m.d, err)) return false;
+    const size_t dp = m.dq * 4;
+    if (!m.scores.ensure(B * m.np, err) || !m.weights.ensure(B * dp, err)) return false;
     m.scores_slots = B;
-    FR_HIP(hipMemcpyAsync(m.weights.p, weights, B * m.d * sizeof(double), hipMemcpyHostToDevice, m.stream));
-    FR_HIP(hipStreamSynchronize(m.stream));  // `weights` is caller memory
+    std::vector<double> wpad(B * dp, 0.0);
+    for (size_t b = 0; b < B; b++) std::memcpy(&wpad[b * dp], weights + b * m.d, m.d * sizeof(double));
+    FR_HIP(hipMemcpyAsync(m.weights.p, wpad.data(), wpad.size() * sizeof(double), hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipStreamSynchronize(m.stream));  // wpad is a local
     {
         ProfScope ps("score_linear_kernel", m.stream);
         if (B >= 8) {
-            dim3 grid((unsigned)((m.n + 255) / 256), (unsigned)((B + 7) / 8));
-            score_linear_kernel<8><<<grid, 256, 0, m.stream>>>(m.xt.p, (uint32_t)m.ld, (uint32_t)m.n,
-                                                               (uint32_t)m.d, m.weights.p, (uint32_t)B, m.scores.p);
+            dim3 grid((unsigned)((m.np + 255) / 256), (unsigned)((B + 7) / 8));
+            score_linear_kernel<8><<<grid, 256, 0, m.stream>>>((const float4*)m.xb.p, (uint32_t)m.np, (uint32_t)m.dq,
+                                                               m.weights.p, (uint32_t)B, m.scores.p);
         } else {
-            dim3 grid((unsigned)((m.n + 255) / 256), (unsigned)B);
-            score_linear_kernel<1><<<grid, 256, 0, m.stream>>>(m.xt.p, (uint32_t)m.ld, (uint32_t)m.n,
-                                                               (uint32_t)m.d, m.weights.p, (uint32_t)B, m.scores.p);
+            dim3 grid((unsigned)((m.np + 255) / 256), (unsigned)B);
+            score_linear_kernel<1><<<grid, 256, 0, m.stream>>>((const float4*)m.xb.p, (uint32_t)m.np, (uint32_t)m.dq,
+                                                               m.weights.p, (uint32_t)B, m.scores.p);
         }
     }
     FR_HIP(hipGetLastError());
@@ -843,14 +987,14 @@ bool DeviceDataset::score_single_feature(uint32_t fid, double dir, std::string* 
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    if (!m.scores.ensure(m.ld, err)) return false;
+    if (!m.scores.ensure(m.np, err)) return false;
     m.scores_slots = 1;
     if (fid >= m.d) {
         // Features::get -> None -> unwrap_or(0.0) for loaded data; dir * 0.0
-        fill_kernel<<<grid1d(m.n, 256), 256, 0, m.stream>>>(m.scores.p, (uint32_t)m.n, dir * 0.0);
+        fill_kernel<<<grid1d(m.np, 256), 256, 0, m.stream>>>(m.scores.p, (uint32_t)m.np, dir * 0.0);
     } else {
-        score_single_feature_kernel<<<grid1d(m.n, 256), 256, 0, m.stream>>>(m.xt.p, (uint32_t)m.ld, (uint32_t)m.n,
-                                                                            fid, dir, m.scores.p);
+        score_single_feature_kernel<<<grid1d(m.np, 256), 256, 0, m.stream>>>(m.xb.p, (uint32_t)m.np, (uint32_t)m.dq, fid,
+                                                                             dir, m.scores.p);
     }
     FR_HIP(hipGetLastError());
     return true;
@@ -860,7 +1004,7 @@ bool DeviceDataset::score_trees(const FlatTrees& t, std::string* err) {
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    if (!m.scores.ensure(m.ld, err)) return false;
+    if (!m.scores.ensure(m.np, err)) return false;
     m.scores_slots = 1;
     size_t nn = t.fid.size(), nt = t.root.size();
     std::vector<TreeNodeDev> nodes(nn);
@@ -880,20 +1024,20 @@ bool DeviceDataset::score_trees(const FlatTrees& t, std::string* err) {
     tw.resize(nt, 1.0);
     FR_HIP(hipMemcpyAsync(m.tweights.p, tw.data(), nt * sizeof(double), hipMemcpyHostToDevice, m.stream));
     FR_HIP(hipStreamSynchronize(m.stream));
-    const unsigned bs = 128;
-    size_t lds = (size_t)bs * (m.d + 1) * sizeof(float);
+    const unsigned bs = 64;  // one tile per block (np is a multiple of 64)
+    size_t lds = (size_t)bs * (m.dq * 4 + 1) * sizeof(float);
     {
         ProfScope ps("tree_ensemble_kernel", m.stream);
         if (lds <= 150 * 1024) {
             FR_HIP(hipFuncSetAttribute((const void*)tree_ensemble_kernel<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            tree_ensemble_kernel<true><<<grid1d(m.n, bs), bs, lds, m.stream>>>(
-                m.xt.p, (uint32_t)m.ld, (uint32_t)m.n, (uint32_t)m.d, m.nodes.p, m.roots.p, m.tweights.p,
-                (uint32_t)nt, t.raw_single ? 1 : 0, m.scores.p);
+            tree_ensemble_kernel<true><<<grid1d(m.np, bs), bs, lds, m.stream>>>(
+                m.xb.p, (uint32_t)m.np, (uint32_t)m.dq, (uint32_t)m.d, m.nodes.p, m.roots.p, m.tweights.p, (uint32_t)nt,
+                t.raw_single ? 1 : 0, m.scores.p);
         } else {
-            tree_ensemble_kernel<false><<<grid1d(m.n, bs), bs, 0, m.stream>>>(
-                m.xt.p, (uint32_t)m.ld, (uint32_t)m.n, (uint32_t)m.d, m.nodes.p, m.roots.p, m.tweights.p,
-                (uint32_t)nt, t.raw_single ? 1 : 0, m.scores.p);
+            tree_ensemble_kernel<false><<<grid1d(m.np, bs), bs, 0, m.stream>>>(
+                m.xb.p, (uint32_t)m.np, (uint32_t)m.dq, (uint32_t)m.d, m.nodes.p, m.roots.p, m.tweights.p, (uint32_t)nt,
+                t.raw_single ? 1 : 0, m.scores.p);
         }
     }
     FR_HIP(hipGetLastError());
@@ -904,8 +1048,8 @@ bool DeviceDataset::ensemble_begin(std::string* err) {
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    if (!m.acc.ensure(m.ld, err)) return false;
-    fill_kernel<<<grid1d(m.n, 256), 256, 0, m.stream>>>(m.acc.p, (uint32_t)m.n, 0.0);
+    if (!m.acc.ensure(m.np, err)) return false;
+    fill_kernel<<<grid1d(m.np, 256), 256, 0, m.stream>>>(m.acc.p, (uint32_t)m.np, 0.0);
     FR_HIP(hipGetLastError());
     return true;
 }
@@ -914,7 +1058,7 @@ bool DeviceDataset::ensemble_accumulate(double w, std::string* err) {
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    axpy_unfused_kernel<<<grid1d(m.n, 256), 256, 0, m.stream>>>(m.acc.p, m.scores.p, (uint32_t)m.n, w);
+    axpy_unfused_kernel<<<grid1d(m.np, 256), 256, 0, m.stream>>>(m.acc.p, m.scores.p, (uint32_t)m.np, w);
     FR_HIP(hipGetLastError());
     return true;
 }
@@ -923,8 +1067,8 @@ bool DeviceDataset::ensemble_finish(std::string* err) {
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    if (!m.scores.ensure(m.ld, err)) return false;
-    FR_HIP(hipMemcpyAsync(m.scores.p, m.acc.p, m.n * sizeof(double), hipMemcpyDeviceToDevice, m.stream));
+    if (!m.scores.ensure(m.np, err)) return false;
+    FR_HIP(hipMemcpyAsync(m.scores.p, m.acc.p, m.np * sizeof(double), hipMemcpyDeviceToDevice, m.stream));
     m.scores_slots = 1;
     return true;
 }
@@ -937,12 +1081,12 @@ bool DeviceDataset::download_scores(size_t b, double* out, size_t out_len, std::
         if (err) *err = "score slot out of range";
         return false;
     }
-    std::vector<double> tmp(m.n);
-    FR_HIP(hipMemcpyAsync(tmp.data(), m.scores.p + b * m.ld, m.n * sizeof(double), hipMemcpyDeviceToHost, m.stream));
+    std::vector<double> tmp(m.np);
+    FR_HIP(hipMemcpyAsync(tmp.data(), m.scores.p + b * m.np, m.np * sizeof(double), hipMemcpyDeviceToHost, m.stream));
     FR_HIP(hipStreamSynchronize(m.stream));
-    for (size_t p = 0; p < m.n; p++) {
+    for (size_t p = 0; p < m.np; p++) {
         size_t id = m.perm_host[p];
-        if (id < out_len) out[id] = tmp[p];
+        if (id != IDX_INVALID && id < out_len) out[id] = tmp[p];
     }
     return true;
 }
@@ -975,10 +1119,10 @@ bool DeviceDataset::metric_from_scores(int measure, int64_t depth, const double*
     {
         ProfScope ps("metric_sort_kernel", m.stream);
         dim3 grid((unsigned)m.nq, (unsigned)B);
-        unsigned bs = npad >= 512 ? 256 : (npad >= 128 ? 64 : 64);
-        metric_sort_kernel<<<grid, bs, lds, m.stream>>>(m.scores.p, (uint32_t)m.ld, m.qoff.p, m.gexp.p, m.gain.p,
-                                                        m.disc.p, m.norms.p, measure, dd, (uint32_t)B, m.M.p,
-                                                        want_rank ? m.rank.p : nullptr, m.perm.p, m.flags.p,
+        unsigned bs = npad >= 512 ? 256 : 64;
+        metric_sort_kernel<<<grid, bs, lds, m.stream>>>(m.scores.p, (uint32_t)m.np, m.qstart.p, m.qlen.p, m.qtight.p,
+                                                        m.gexp.p, m.gain.p, m.disc.p, m.norms.p, measure, dd, (uint32_t)B,
+                                                        m.M.p, want_rank ? m.rank.p : nullptr, m.perm.p, m.flags.p,
                                                         (uint32_t)npad);
     }
     FR_HIP(hipGetLastError());
@@ -1032,30 +1176,29 @@ bool DeviceDataset::reduce_means(size_t ncols, double* out, std::string* err) {
         if (err) *err = "reduce_means: shape mismatch";
         return false;
     }
-    if (!launch_means(this, m.M.p, m.last_ldm, ncols, m.nq, m.partial, m.means, m.stream, err)) return false;
+    if (!launch_means(m.M.p, m.last_ldm, ncols, m.nq, m.partial, m.means, m.stream, err)) return false;
     FR_HIP(hipMemcpyAsync(out, m.means.p, ncols * sizeof(double), hipMemcpyDeviceToHost, m.stream));
     FR_HIP(hipStreamSynchronize(m.stream));
     return true;
 }
 
-bool DeviceDataset::linesearch_supported(int measure, int64_t depth) {
-    return measure == M_NDCG && depth >= 0 && depth <= 20;
+bool DeviceDataset::linesearch_supported(int measure, int64_t depth) const {
+    // zero-weight masking is exact only for finite features (inf * 0 = NaN)
+    return measure == M_NDCG && depth >= 0 && depth <= 20 && !impl_->nonfinite && impl_->dq * 4 <= 2048;
 }
 
-size_t DeviceDataset::linesearch_max_features() { return LS_MAXD; }
-
 template <int K, int CT>
-static void launch_linesearch(const LSArgs& a, unsigned nblocks, hipStream_t st) {
-    linesearch_ndcg_kernel<K, CT, 16><<<dim3(nblocks), dim3(WAVE), 0, st>>>(a);
+static void launch_linesearch(const LSArgs& a, unsigned nblocks, size_t lds, hipStream_t st) {
+    linesearch_ndcg_kernel<K, CT, 16><<<dim3(nblocks), dim3(WAVE), lds, st>>>(a);
 }
 
 template <int K>
-static void dispatch_ct(const LSArgs& a, unsigned nblocks, size_t maxc, hipStream_t st) {
-    if (maxc <= 4) launch_linesearch<K, 4>(a, nblocks, st);
-    else if (maxc <= 16) launch_linesearch<K, 16>(a, nblocks, st);
-    else if (maxc <= 32) launch_linesearch<K, 32>(a, nblocks, st);
-    else if (maxc <= 52) launch_linesearch<K, 52>(a, nblocks, st);
-    else launch_linesearch<K, 64>(a, nblocks, st);
+static void dispatch_ct(const LSArgs& a, unsigned nblocks, size_t maxc, size_t lds, hipStream_t st) {
+    if (maxc <= 4) launch_linesearch<K, 4>(a, nblocks, lds, st);
+    else if (maxc <= 16) launch_linesearch<K, 16>(a, nblocks, lds, st);
+    else if (maxc <= 32) launch_linesearch<K, 32>(a, nblocks, lds, st);
+    else if (maxc <= 52) launch_linesearch<K, 52>(a, nblocks, lds, st);
+    else launch_linesearch<K, 64>(a, nblocks, lds, st);
 }
 
 bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
@@ -1063,16 +1206,17 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
-    if (!linesearch_supported(M_NDCG, depth) || m.d > (size_t)LS_MAXD) {
-        if (err) *err = "linesearch_ndcg: unsupported depth or feature count";
+    if (!linesearch_supported(M_NDCG, depth)) {
+        if (err) *err = "linesearch_ndcg: unsupported depth, feature count or non-finite features";
         return false;
     }
     const size_t G = groups.size();
     means->assign(G * 64, 0.0);
     if (G == 0) return true;
+    const size_t dp = m.dq * 4;
     size_t maxc = 0;
     std::vector<uint32_t> gfeat(G), gncand(G);
-    std::vector<double> gw(G * m.d), gcand(G * 64, 0.0);
+    std::vector<double> gw(G * dp, 0.0), gcand(G * 64, 0.0);
     for (size_t g = 0; g < G; g++) {
         const LineGroup& lg = groups[g];
         if (lg.feature >= m.d || lg.weights.size() != m.d || lg.candidates.empty() || lg.candidates.size() > 64) {
@@ -1082,24 +1226,30 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
         gfeat[g] = lg.feature;
         gncand[g] = (uint32_t)lg.candidates.size();
         maxc = std::max(maxc, lg.candidates.size());
-        std::memcpy(&gw[g * m.d], lg.weights.data(), m.d * sizeof(double));
+        std::memcpy(&gw[g * dp], lg.weights.data(), m.d * sizeof(double));
         std::memcpy(&gcand[g * 64], lg.candidates.data(), lg.candidates.size() * sizeof(double));
     }
     const size_t ldm = G * 64;
     if (!m.M.ensure(m.nq * ldm, err) || !m.norms.ensure(m.nq, err) || !m.gfeat.ensure(G, err) ||
-        !m.gncand.ensure(G, err) || !m.gw.ensure(G * m.d, err) || !m.gcand.ensure(G * 64, err) ||
+        !m.gncand.ensure(G, err) || !m.gw.ensure(G * dp, err) || !m.gcand.ensure(G * 64, err) ||
         !m.means.ensure(ldm, err))
         return false;
     FR_HIP(hipMemcpyAsync(m.norms.p, norms, m.nq * sizeof(double), hipMemcpyHostToDevice, m.stream));
     FR_HIP(hipMemcpyAsync(m.gfeat.p, gfeat.data(), G * sizeof(uint32_t), hipMemcpyHostToDevice, m.stream));
     FR_HIP(hipMemcpyAsync(m.gncand.p, gncand.data(), G * sizeof(uint32_t), hipMemcpyHostToDevice, m.stream));
-    FR_HIP(hipMemcpyAsync(m.gw.p, gw.data(), G * m.d * sizeof(double), hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipMemcpyAsync(m.gw.p, gw.data(), G * dp * sizeof(double), hipMemcpyHostToDevice, m.stream));
     FR_HIP(hipMemcpyAsync(m.gcand.p, gcand.data(), G * 64 * sizeof(double), hipMemcpyHostToDevice, m.stream));
     LSArgs a;
-    a.xt = m.xt.p;
-    a.gexp = m.gexp.p;
-    a.qoff = m.qoff.p;
-    a.qorder = m.qorder.p;
+    a.xb = (const float4*)m.xb.p;
+    a.gcls = m.gcls.p;
+    a.dcgtab = m.dcgtab.p;
+    a.qstart = m.qstart.p;
+    a.qlen = m.qlen.p;
+    a.run_q0 = m.run_q0.p;
+    a.run_q1 = m.run_q1.p;
+    a.run_pos = m.run_pos.p;
+    a.run_docs = m.run_docs.p;
+    a.run_order = m.run_order.p;
     a.norms = m.norms.p;
     a.disc = m.disc.p;
     a.gfeat = m.gfeat.p;
@@ -1108,42 +1258,41 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
     a.gncand = m.gncand.p;
     a.M = m.M.p;
     a.flags = m.flags.p;
-    if (!m.dbgc.ensure(4, err)) return false;
     a.dbg_counters = m.dbgc.p;
-    a.ld = (uint32_t)m.ld;
+    a.dq = (uint32_t)m.dq;
     a.d = (uint32_t)m.d;
-    a.nq = (uint32_t)m.nq;
+    a.nruns = (uint32_t)m.nruns;
     a.G = (uint32_t)G;
     a.ldm = (uint32_t)ldm;
     a.depth = (int)depth;
     {
         const char* dbg = getenv("FR_LS_DEBUG");
         a.debug = dbg ? atoi(dbg) : 0;
-        if (a.debug & 16) FR_HIP(hipMemsetAsync(m.dbgc.p, 0, 4 * sizeof(uint64_t), m.stream));
+        if (a.debug & 16) FR_HIP(hipMemsetAsync(m.dbgc.p, 0, 4 * sizeof(unsigned long long), m.stream));
     }
-    const size_t nblocks = ((m.nq + 7) / 8) * 8 * G;
+    const size_t nblocks = ((m.nruns + 7) / 8) * 8 * G;
     if (nblocks > 0x7fffffffull) {
         if (err) *err = "linesearch_ndcg: grid too large";
         return false;
     }
+    const size_t lds = 2 * dp * sizeof(double);
     {
         ProfScope ps("linesearch_ndcg_kernel", m.stream);
-        if (depth <= 5) dispatch_ct<5>(a, (unsigned)nblocks, maxc, m.stream);
-        else if (depth <= 10) dispatch_ct<10>(a, (unsigned)nblocks, maxc, m.stream);
-        else dispatch_ct<20>(a, (unsigned)nblocks, maxc, m.stream);
+        if (depth <= 5) dispatch_ct<5>(a, (unsigned)nblocks, maxc, lds, m.stream);
+        else if (depth <= 10) dispatch_ct<10>(a, (unsigned)nblocks, maxc, lds, m.stream);
+        else dispatch_ct<20>(a, (unsigned)nblocks, maxc, lds, m.stream);
     }
     FR_HIP(hipGetLastError());
-    if (!launch_means(this, m.M.p, ldm, ldm, m.nq, m.partial, m.means, m.stream, err)) return false;
+    if (!launch_means(m.M.p, ldm, ldm, m.nq, m.partial, m.means, m.stream, err)) return false;
     FR_HIP(hipMemcpyAsync(means->data(), m.means.p, ldm * sizeof(double), hipMemcpyDeviceToHost, m.stream));
     m.last_ldm = ldm;
     m.last_cols = ldm;
     if (a.debug & 16) {
-        uint64_t c[4];
+        unsigned long long c[4];
         FR_HIP(hipMemcpyAsync(c, m.dbgc.p, sizeof(c), hipMemcpyDeviceToHost, m.stream));
         FR_HIP(hipStreamSynchronize(m.stream));
-        fprintf(stderr, "[FR_LS_DEBUG] docs=%llu rows=%llu (%.3f of docs) batches=%llu insertion_rows=%llu\n",
-                (unsigned long long)c[3], (unsigned long long)c[0], (double)c[0] / (double)c[3], (unsigned long long)c[1],
-                (unsigned long long)c[2]);
+        fprintf(stderr, "[FR_LS_DEBUG] docs=%llu rows=%llu (%.3f of docs) batches=%llu insertion_rows=%llu\n", c[3], c[0],
+                (double)c[0] / (double)c[3], c[1], c[2]);
     }
     return m.pull_flags(err);
 }

@@ -5,7 +5,8 @@
 //   * documents regrouped by query (CSR), and inside each query stored in REVERSE tie-break
 //     order (gain desc, instance-id desc) so that "later document wins score ties" reproduces
 //     the reference's (score desc, gain asc, id asc) total order (src/evaluators.rs:34-49);
-//   * features column-major f32 [D][ld] (ld = N rounded up to 64) for coalesced lane=doc reads;
+//   * consecutive queries are packed into "runs" of whole 64-document tiles; features live in
+//     tiles [tile][D/4][64 docs][4 features] f32, so lane = document reads 16 B per load;
 //   * per-document gain (f32), 2^gain-1 (f64, host libm like the reference), relevance flag;
 //   * per-query offsets, a longest-first query schedule, log2(i+2) discount table.
 #pragma once
@@ -91,8 +92,8 @@ class DeviceDataset {
     bool reduce_means(size_t ncols, double* out_means, std::string* err);
 
     // --- fused line search (NDCG@k, k <= 20) --------------------------------------------------
-    static bool linesearch_supported(int measure, int64_t depth);
-    static size_t linesearch_max_features();
+    // false for non-NDCG@k measures, k > 20, and datasets with non-finite features
+    bool linesearch_supported(int measure, int64_t depth) const;
     // evaluates every candidate of every group; means[g*64 + c]
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);

@@ -721,8 +721,7 @@ class CATrainer {
         std::vector<uint64_t> child(p_.num_restarts);
         for (uint32_t r = 0; r < p_.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
         for (uint32_t r = rbegin; r < rend; r++) rs_.emplace_back(r, child[r]);
-        fused_ = frdev::DeviceDataset::linesearch_supported(ev_.measure, ev_.depth) &&
-                 d_ <= frdev::DeviceDataset::linesearch_max_features();
+        fused_ = dev.linesearch_supported(ev_.measure, ev_.depth);
         stats_.path = fused_ ? "fused_linesearch" : "generic_sort";
         stats_.restarts = (uint32_t)rs_.size();
         if (rs_.empty()) return;
