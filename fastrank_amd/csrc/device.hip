@@ -224,26 +224,27 @@ __global__ void axpy_unfused_kernel(double* __restrict__ acc, const double* __re
 }
 
 struct TreeNodeDev {
-    double split;  // or leaf value
-    int32_t fid;   // <0: leaf
-    int32_t lhs, rhs;
-    int32_t pad;
+    double split;  // threshold, or the leaf value when fid < 0
+    int32_t fid;   // < 0: leaf
+    int32_t lhs;   // left child; the right child is lhs + 1 (children are stored adjacently)
 };
 
 // Batched tree-ensemble scoring (src/model.rs:64-84,104-112; config 5 of BASELINE.json).
-// One thread = one document.  With ROWS_IN_LDS the block first stages its documents' feature
-// rows from the tiles into LDS (16-byte loads in, row stride d+1 dwords so lane-strided accesses
-// spread over the banks), then every tree walk reads features from LDS; node records come from
-// L1/L2 (all lanes walk the same tree).
-template <bool ROWS_IN_LDS>
-__global__ __launch_bounds__(128) void tree_ensemble_kernel(const float* __restrict__ xb, uint32_t np, uint32_t dq,
-                                                            uint32_t d, const TreeNodeDev* __restrict__ nodes,
-                                                            const int32_t* __restrict__ roots,
-                                                            const double* __restrict__ tw, uint32_t ntrees,
-                                                            int raw_single, double* __restrict__ scores) {
-    extern __shared__ float rows[];  // [blockDim.x][4*dq+1]
+// One thread = one document, one 64-document tile per block.  The block first stages its
+// documents' feature rows from the tile into LDS (16-byte loads in, row stride 4*dq+1 dwords so
+// lane-strided accesses spread over the banks).  Each lane then walks TI trees at once (TI
+// independent pointer chases hide the L1/L2 latency of the 16-byte node records; all lanes walk
+// the same trees, so the records stay cache resident) and adds the leaves in tree order:
+// out += w_t * leaf_t, unfused (src/model.rs:104-112).
+template <bool ROWS_IN_LDS, int TI>
+__global__ __launch_bounds__(64) void tree_ensemble_kernel(const float* __restrict__ xb, uint32_t np, uint32_t dq,
+                                                           uint32_t d, const TreeNodeDev* __restrict__ nodes,
+                                                           const int32_t* __restrict__ roots,
+                                                           const double* __restrict__ tw, uint32_t ntrees,
+                                                           int raw_single, double* __restrict__ scores) {
+    extern __shared__ float rows[];  // [64][4*dq+1]
     const uint32_t tid = threadIdx.x;
-    const uint32_t p = blockIdx.x * blockDim.x + tid;  // np is a multiple of 64 and of the block size
+    const uint32_t p = blockIdx.x * blockDim.x + tid;  // np is a multiple of 64
     const uint32_t rs = dq * 4 + 1;
     if (ROWS_IN_LDS) {
         const float4* xp = (const float4*)xb + (size_t)(p >> 6) * dq * 64 + (p & 63);
@@ -257,25 +258,41 @@ __global__ __launch_bounds__(128) void tree_ensemble_kernel(const float* __restr
         }
         __syncthreads();
     }
+    const float* myrow = rows + tid * rs;
     double acc = 0.0;
-    for (uint32_t t = 0; t < ntrees; t++) {
-        int32_t node = roots[t];
-        TreeNodeDev nd = nodes[node];
-        while (nd.fid >= 0) {
-            float xv;
-            if ((uint32_t)nd.fid < d) {
-                xv = ROWS_IN_LDS ? rows[tid * rs + (uint32_t)nd.fid] : xb[xb_index(p, (uint32_t)nd.fid, dq)];
-            } else {
-                xv = 0.0f;  // Features::get -> None -> unwrap_or(0.0) (src/model.rs:72-73)
+    for (uint32_t t0 = 0; t0 < ntrees; t0 += TI) {
+        TreeNodeDev nd[TI];
+#pragma unroll
+        for (int k = 0; k < TI; k++) nd[k] = nodes[roots[t0 + k < ntrees ? t0 + k : ntrees - 1]];
+        bool any_inner = true;
+        while (any_inner) {
+            any_inner = false;
+#pragma unroll
+            for (int k = 0; k < TI; k++) {
+                if (nd[k].fid >= 0) {
+                    float xv;
+                    if ((uint32_t)nd[k].fid < d) {
+                        xv = ROWS_IN_LDS ? myrow[(uint32_t)nd[k].fid] : xb[xb_index(p, (uint32_t)nd[k].fid, dq)];
+                    } else {
+                        xv = 0.0f;  // Features::get -> None -> unwrap_or(0.0) (src/model.rs:72-73)
+                    }
+                    const int32_t next = ((double)xv <= nd[k].split) ? nd[k].lhs : nd[k].lhs + 1;
+                    nd[k] = nodes[next];
+                    any_inner |= nd[k].fid >= 0;
+                }
             }
-            node = ((double)xv <= nd.split) ? nd.lhs : nd.rhs;
-            nd = nodes[node];
+            any_inner = __any(any_inner);
         }
-        if (raw_single) {
-            acc = nd.split;
-        } else {
-            double prod = tw[t] * nd.split;
-            acc = acc + prod;
+#pragma unroll
+        for (int k = 0; k < TI; k++) {
+            if (t0 + k < ntrees) {
+                if (raw_single) {
+                    acc = nd[k].split;
+                } else {
+                    double prod = tw[t0 + k] * nd[k].split;
+                    acc = acc + prod;
+                }
+            }
         }
     }
     if (p < np) scores[p] = acc;
@@ -1006,20 +1023,40 @@ bool DeviceDataset::score_trees(const FlatTrees& t, std::string* err) {
     if (!m.bind(err)) return false;
     if (!m.scores.ensure(m.np, err)) return false;
     m.scores_slots = 1;
-    size_t nn = t.fid.size(), nt = t.root.size();
-    std::vector<TreeNodeDev> nodes(nn);
-    for (size_t k = 0; k < nn; k++) {
-        nodes[k].split = t.split[k];
-        nodes[k].fid = t.fid[k];
-        nodes[k].lhs = t.lhs[k];
-        nodes[k].rhs = t.rhs[k];
-        nodes[k].pad = 0;
+    const size_t nt = t.root.size();
+    // re-lay the forest out so that the two children of a node are adjacent (rhs = lhs + 1)
+    std::vector<TreeNodeDev> nodes;
+    std::vector<int32_t> roots(nt);
+    nodes.reserve(t.fid.size() + nt);
+    {
+        std::vector<std::pair<int32_t, int32_t>> work;  // (source node, destination slot)
+        for (size_t k = 0; k < nt; k++) {
+            roots[k] = (int32_t)nodes.size();
+            nodes.push_back(TreeNodeDev{0.0, -1, 0});
+            work.emplace_back(t.root[k], roots[k]);
+            while (!work.empty()) {
+                auto [src, dst] = work.back();
+                work.pop_back();
+                nodes[dst].split = t.split[src];
+                nodes[dst].fid = t.fid[src];
+                nodes[dst].lhs = 0;
+                if (t.fid[src] >= 0) {
+                    int32_t kids = (int32_t)nodes.size();
+                    nodes[dst].lhs = kids;
+                    nodes.push_back(TreeNodeDev{0.0, -1, 0});
+                    nodes.push_back(TreeNodeDev{0.0, -1, 0});
+                    work.emplace_back(t.lhs[src], kids);
+                    work.emplace_back(t.rhs[src], kids + 1);
+                }
+            }
+        }
     }
+    const size_t nn = nodes.size();
     if (!m.nodes.ensure(std::max<size_t>(nn, 1), err) || !m.roots.ensure(std::max<size_t>(nt, 1), err) ||
         !m.tweights.ensure(std::max<size_t>(nt, 1), err))
         return false;
     FR_HIP(hipMemcpyAsync(m.nodes.p, nodes.data(), nn * sizeof(TreeNodeDev), hipMemcpyHostToDevice, m.stream));
-    FR_HIP(hipMemcpyAsync(m.roots.p, t.root.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipMemcpyAsync(m.roots.p, roots.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice, m.stream));
     std::vector<double> tw = t.weight;
     tw.resize(nt, 1.0);
     FR_HIP(hipMemcpyAsync(m.tweights.p, tw.data(), nt * sizeof(double), hipMemcpyHostToDevice, m.stream));
@@ -1029,13 +1066,13 @@ bool DeviceDataset::score_trees(const FlatTrees& t, std::string* err) {
     {
         ProfScope ps("tree_ensemble_kernel", m.stream);
         if (lds <= 150 * 1024) {
-            FR_HIP(hipFuncSetAttribute((const void*)tree_ensemble_kernel<true>,
+            FR_HIP(hipFuncSetAttribute((const void*)tree_ensemble_kernel<true, 8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            tree_ensemble_kernel<true><<<grid1d(m.np, bs), bs, lds, m.stream>>>(
+            tree_ensemble_kernel<true, 8><<<grid1d(m.np, bs), bs, lds, m.stream>>>(
                 m.xb.p, (uint32_t)m.np, (uint32_t)m.dq, (uint32_t)m.d, m.nodes.p, m.roots.p, m.tweights.p, (uint32_t)nt,
                 t.raw_single ? 1 : 0, m.scores.p);
         } else {
-            tree_ensemble_kernel<false><<<grid1d(m.np, bs), bs, 0, m.stream>>>(
+            tree_ensemble_kernel<false, 8><<<grid1d(m.np, bs), bs, 0, m.stream>>>(
                 m.xb.p, (uint32_t)m.np, (uint32_t)m.dq, (uint32_t)m.d, m.nodes.p, m.roots.p, m.tweights.p, (uint32_t)nt,
                 t.raw_single ? 1 : 0, m.scores.p);
         }
