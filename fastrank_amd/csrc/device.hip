@@ -592,7 +592,6 @@ __global__ __launch_bounds__(WAVE, LS_WAVES_PER_SIMD) void linesearch_ndcg_kerne
         const double xf = (double)((const float*)(tile + (size_t)fgrp * 64))[fsub];
         // two tile groups of the suffix are requested before the candidate initialisation
         float4 x0 = tile[(size_t)(sq0 < dq ? sq0 : dq - 1) * 64];
-        float4 x1 = tile[(size_t)(sq0 + 1 < dq ? sq0 + 1 : dq - 1) * 64];
         double sc[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
@@ -600,7 +599,7 @@ __global__ __launch_bounds__(WAVE, LS_WAVES_PER_SIMD) void linesearch_ndcg_kerne
             sc[c] = P + prod;
         }
         for (uint32_t j4 = sq0; j4 < dq; j4++) {
-            const float4 x2 = tile[(size_t)(j4 + 2 < dq ? j4 + 2 : dq - 1) * 64];
+            const float4 x2 = tile[(size_t)(j4 + 1 < dq ? j4 + 1 : dq - 1) * 64];
             const double* wp = wsuf + j4 * 4;
             const float xs[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
@@ -609,8 +608,7 @@ __global__ __launch_bounds__(WAVE, LS_WAVES_PER_SIMD) void linesearch_ndcg_kerne
 #pragma unroll
                 for (int c = 0; c < CT; c++) sc[c] = sc[c] + prod;
             }
-            x0 = x1;
-            x1 = x2;
+            x0 = x2;
         }
         // ---------------- filter + transpose + phase K: lane = candidate ----------------
         const uint32_t nvalid = (run_end - pb) < (uint32_t)WAVE ? (run_end - pb) : (uint32_t)WAVE;
@@ -1234,7 +1232,7 @@ static void dispatch_ct(const LSArgs& a, unsigned nblocks, size_t maxc, size_t l
     if (maxc <= 4) launch_linesearch<K, 4>(a, nblocks, lds, st);
     else if (maxc <= 16) launch_linesearch<K, 16>(a, nblocks, lds, st);
     else if (maxc <= 32) launch_linesearch<K, 32>(a, nblocks, lds, st);
-    else if (maxc <= 52) launch_linesearch<K, 52>(a, nblocks, lds, st);
+    else if (maxc <= 51) launch_linesearch<K, 51>(a, nblocks, lds, st);
     else launch_linesearch<K, 64>(a, nblocks, lds, st);
 }
 

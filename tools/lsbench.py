@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=25)
     ap.add_argument("--measure", default="ndcg@10")
     ap.add_argument("--feature", type=int, default=-1, help="fixed feature for all groups (-1 = random)")
+    ap.add_argument("--calib", action="store_true", help="also run score_linear_kernel once (reads the matrix exactly once: FETCH_SIZE calibration)")
     args = ap.parse_args()
     n, d, q, seed = bench.SHAPES[args.shape]
     X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
@@ -53,6 +54,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.reps):
         means = native.evaluate_candidates(ds, args.measure, feats, bases, cands)
+    if args.calib:
+        m = fr.CModel.from_dict({"Linear": {"weights": bases[0].tolist()}})
+        native.predict_scores_dense(m, ds, n)
     native.synchronize()
     wall = (time.perf_counter() - t0) / args.reps
     native.profile_enable(False)
