@@ -1,0 +1,104 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the CPU oracle is
+only run on a sample of queries here; the small-size tests hold the bit-exact comparisons)."""
+import numpy as np
+import pytest
+
+import bench
+import fastrank_amd as fr
+from fastrank_amd import native
+from oracle import pyoracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["10k", "30k"])
+def big(request):
+    n, d, q, seed = bench.SHAPES[request.param]
+    X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
+    return request.param, X, y, qid, fr.CDataset.from_numpy(X, y, qid)
+
+
+def _groups(rng, d, G):
+    feats, bases, cands = [], [], []
+    for _ in range(G):
+        w = rng.uniform(-1, 1, d)
+        w /= np.abs(w).sum()
+        f = int(rng.integers(0, d))
+        feats.append(f), bases.append(w), cands.append(o.ca_candidates(w[f], 0.05, 2.0, 25))
+    return feats, np.asarray(bases), cands
+
+
+def test_fused_kernel_properties_at_full_size(big):
+    name, X, y, qid, g = big
+    rng = np.random.default_rng(101)
+    feats, bases, cands = _groups(rng, X.shape[1], 2)
+    means, pq = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands, per_query=True)
+    nq = native.num_queries(g)
+    assert pq.shape == (nq, 2 * 64)
+    for gi in range(2):
+        cols = pq[:, gi * 64: gi * 64 + 51]
+        assert np.isfinite(cols).all() and cols.min() >= 0.0 and cols.max() <= 1.0
+        # fixed summation shape: 256-query segments, then the partials (device.hip MEAN_SEG)
+        for ci in (0, 17, 50):
+            v = cols[:, ci]
+            seg = [np.add.reduce(np.concatenate([[0.0], v[s:s + 256]])) for s in range(0, nq, 256)]
+            # np.add.reduce is pairwise; rebuild the exact sequential sums in Python floats
+            tot = 0.0
+            for s in range(0, nq, 256):
+                part = 0.0
+                for t in v[s:s + 256].tolist():
+                    part += t
+                tot += part
+            assert means[gi][ci] == tot / nq
+    # cross-check against the independent general path (ordered scoring kernel + LDS bitonic sort)
+    sel = [(0, 0), (0, 26), (1, 50)]
+    for gi, ci in sel:
+        w = bases[gi].copy()
+        w[feats[gi]] = cands[gi][ci]
+        m = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+        qids, vals = native.evaluate_dense(m, g, "ndcg@10")
+        assert np.array_equal(vals, pq[:, gi * 64 + ci]), (name, gi, ci)
+    # dir-0 candidate == the base weights with that coordinate zeroed (coordinate_ascent.rs:152-155)
+    assert cands[0][0] == 0.0
+
+
+def test_rank_order_is_sorted_and_a_permutation_at_full_size(big):
+    name, X, y, qid, g = big
+    rng = np.random.default_rng(103)
+    w = rng.uniform(-1, 1, X.shape[1])
+    m = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+    scores = native.predict_scores_dense(m, g, len(y))
+    ids, offs = native.rank_order(m, g)
+    assert np.array_equal(np.sort(ids), np.arange(len(y), dtype=np.uint32))
+    s = scores[ids]
+    gains = y[ids].astype(np.float32)
+    same_q = np.ones(len(ids), dtype=bool)
+    same_q[offs[1:-1].astype(np.int64)] = False  # first element of every query but the first
+    same_q[0] = False
+    prev_s, prev_g, prev_id = np.roll(s, 1), np.roll(gains, 1), np.roll(ids, 1)
+    ok = (prev_s > s) | ((prev_s == s) & ((prev_g < gains) | ((prev_g == gains) & (prev_id < ids))))
+    assert ok[same_q].all(), "score desc, gain asc, id asc within every query"
+    assert np.array_equal(qid[ids[offs[:-1].astype(np.int64)]], qid[ids[(offs[1:] - 1).astype(np.int64)]])
+
+
+def test_sampled_queries_match_the_oracle_at_full_size(big):
+    name, X, y, qid, g = big
+    rng = np.random.default_rng(107)
+    feats, bases, cands = _groups(rng, X.shape[1], 1)
+    _, pq = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands, per_query=True)
+    uq = np.unique(qid)
+    pick = np.sort(rng.choice(len(uq), 150, replace=False))
+    mask = np.isin(qid, uq[pick])
+    c = o.Dataset(X[mask], y[mask], qid[mask])
+    # device query order is first appearance = ascending qid here, same as the oracle's
+    for ci in (0, 9, 33, 50):
+        w = bases[0].copy()
+        w[feats[0]] = cands[0][ci]
+        exp, err = c.metric_from_scores("ndcg@10", c.score_linear(w))
+        assert err == 0
+        assert np.array_equal(pq[pick, ci], exp), (name, ci)
+    m = fr.CModel.from_dict({"Linear": {"weights": bases[0].tolist()}})
+    for measure in ("map", "mrr", "ndcg"):
+        _, vals = native.evaluate_dense(m, g, measure)
+        exp, _ = c.metric_from_scores(measure, c.score_linear(bases[0]))
+        assert np.array_equal(vals[pick], exp), (name, measure)

@@ -454,3 +454,95 @@ def test_mean_summation_shape_many_queries():
         assert shard["stats"]["useful_evals"] == int(exp_e.sum())
     finally:
         o.set_mean_segment(0)
+
+
+def test_tiny_queries_many_boundaries_per_tile_and_odd_feature_count():
+    """Queries of 1-3 documents: dozens of query boundaries inside one 64-document tile, 13
+    features (not a multiple of the 4-feature tile group)."""
+    rng = np.random.default_rng(43)
+    lens = rng.integers(1, 4, size=400)
+    qid = np.repeat(np.arange(7, 7 + len(lens), dtype=np.int64), lens)
+    n = len(qid)
+    X = np.round(rng.normal(0, 2, (n, 13))).astype(np.float32)
+    y = rng.choice([0.0, 0.0, 1.0, 2.0, 3.5], size=n)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    feats, bases, cands = _ca_groups(rng, 13, 3, iters=25)
+    feats = [0, 12, 5]
+    cands = [o.ca_candidates(bases[i][feats[i]], 0.05, 2.0, 25) for i in range(3)]
+    try:
+        o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+        for measure in ("ndcg@10", "ndcg@2"):
+            means, pq = native.evaluate_candidates(g, measure, feats, bases, cands, per_query=True)
+            for gi in range(3):
+                for ci in (0, 1, 13, 50):
+                    w = bases[gi].copy()
+                    w[feats[gi]] = cands[gi][ci]
+                    exp, _ = c.metric_from_scores(measure, c.score_linear(w))
+                    assert np.array_equal(pq[:, gi * 64 + ci], exp), (measure, gi, ci)
+                    assert means[gi][ci] == c.evaluate_mean(measure, w)
+    finally:
+        o.set_mean_segment(0)
+
+
+def test_more_than_64_candidates_per_line_search(trec):
+    """num_max_iterations = 40 -> 81 candidates per feature -> two 64-wide line groups."""
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations, p.step_scale = 3, True, 2, 40, 1.3
+    shard = native.train_model_shard(g, req, 0, 2)
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+    assert shard["stats"]["path"] == "fused_linesearch"
+
+
+def test_infinite_features_take_the_general_path(trec):
+    """inf * 0 = NaN would break zero-weight masking, so such datasets must not use the fused
+    kernel; results still match the oracle (inf scores are legal, NaN scores are an error)."""
+    X = trec["train_X"].copy()
+    y, qid = trec["train_y"], trec["train_qid"]
+    X[5, 1] = np.inf
+    X[40, 4] = -np.inf
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    w = np.array([0.0, 0.4, 0.1, 0.2, 0.3, 0.5])
+    base = w[None, :].copy()
+    cands = [np.asarray([0.0, 0.1, 0.7])]
+    means = native.evaluate_candidates(g, "ndcg@10", [2], base, cands)
+    for ci, cv in enumerate(cands[0]):
+        ww = w.copy()
+        ww[2] = cv
+        assert means[0][ci] == c.evaluate_mean("ndcg@10", ww)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    req.params.seed, req.params.quiet, req.params.num_restarts, req.params.num_max_iterations = 1, True, 1, 2
+    req.params.init_random = False
+    req.params.normalize = False
+    with pytest.raises(Exception, match="NaN"):
+        g.train_model(req)  # dir 0 makes a weight 0.0 -> inf * 0 = NaN -> the reference panics too
+    assert native.last_train_stats is not None
+
+
+def test_ranksvm_file_and_numpy_entry_points_train_identically(trec, known):
+    rd = fr.CDataset.open_ranksvm(os.path.join(GOLDEN, "data", "trec_news_2018.train"))
+    dense = fr.CDataset.from_numpy(trec["train_X"], trec["train_y"], trec["train_qid"])
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@5"
+    req.params.seed, req.params.quiet, req.params.num_restarts, req.params.num_max_iterations = 9, True, 2, 4
+    a, b = rd.train_model(req).to_dict(), dense.train_model(req).to_dict()
+    assert a == b
+    # a query-sampled view trains on exactly its queries (tests/test_with_example_data.py:106-137)
+    subset = sorted(known["expected_queries"])[:12]
+    part = rd.subsample_queries(subset)
+    mask = np.isin(trec["train_qid"], [int(q) for q in subset])
+    c = o.Dataset(trec["train_X"][mask], trec["train_y"][mask], trec["train_qid"][mask])
+    shard = native.train_model_shard(part, req, 0, 2)
+    exp_s, exp_w, _, _ = c.ca_learn("ndcg@5", req.params.to_dict(), threads=2)
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    sparse = fr.CModel.from_dict(a).predict_scores(part)
+    assert len(sparse) == part.num_instances() == int(mask.sum())
