@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -291,6 +292,119 @@ __global__ __launch_bounds__(64) void tree_ensemble_kernel(const float* __restri
                 } else {
                     double prod = tw[t0 + k] * nd[k].split;
                     acc = acc + prod;
+                }
+            }
+        }
+    }
+    if (p < np) scores[p] = acc;
+}
+
+// Compact forest for the LDS walk.  One 8-byte word per node; children adjacent (right = left + 1):
+//   internal: { float thr; u16 fid; u16 left }   thr = largest f32 <= split, so for every f32 x
+//             (f64(x) <= split)  <=>  (x <= thr)          (src/model.rs:75-79)
+//   leaf:     { 0; 0xFFFF; u16 index into this tree's f64 leaf table }
+constexpr uint32_t LDS_TREES_PER_BATCH = 64;  // upper bound on trees per LDS batch
+
+struct PackedNode {
+    float thr;
+    uint16_t fid;
+    uint16_t ref;
+};
+
+// Batched tree-ensemble scoring, LDS-resident trees (the fast path of config 5).
+// Block = `blockDim.x / 64` tiles of documents, one thread per document: feature rows staged in LDS
+// (row stride 4*dq+1 dwords), then the forest streams through LDS in batches (words + f64 leaves,
+// coalesced copy); every lane walks TI trees of the batch concurrently, `levels` steps each
+// (leaves stay put), and adds the leaves in tree order: out += w_t * leaf_t, unfused.
+template <int TI>
+__global__ __launch_bounds__(256) void tree_ensemble_lds_kernel(
+    const float* __restrict__ xb, uint32_t np, uint32_t dq, uint32_t d, const uint64_t* __restrict__ forest,
+    const uint32_t* __restrict__ batch_off /*[nbatch+1] in 8-byte words*/, const uint32_t* __restrict__ tree_meta
+    /*[ntrees][3]: word offset of root inside its batch, word offset of its leaf table, levels*/,
+    const uint32_t* __restrict__ batch_first /*[nbatch+1] first tree of each batch*/,
+    const double* __restrict__ tw, uint32_t nbatch, int raw_single, uint32_t tree_words_cap,
+    double* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw8[];
+    uint64_t* trees = (uint64_t*)lds_raw8;                   // [tree_words_cap]
+    double* bw = (double*)(trees + tree_words_cap);          // [LDS_TREES_PER_BATCH] tree weights of the batch
+    uint32_t* bmeta = (uint32_t*)(bw + LDS_TREES_PER_BATCH); // [LDS_TREES_PER_BATCH][4]
+    float* rows = (float*)(bmeta + LDS_TREES_PER_BATCH * 4); // [blockDim.x][4*dq+1]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t p = blockIdx.x * blockDim.x + tid;        // np is a multiple of 64; p may exceed np in the last block
+    const uint32_t pc = p < np ? p : np - 1;
+    const uint32_t rs = dq * 4 + 1;
+    {
+        const float4* xp = (const float4*)xb + (size_t)(pc >> 6) * dq * 64 + (pc & 63);
+        for (uint32_t j4 = 0; j4 < dq; j4++) {
+            float4 v = xp[(size_t)j4 * 64];
+            float* r = rows + tid * rs + j4 * 4;
+            r[0] = v.x;
+            r[1] = v.y;
+            r[2] = v.z;
+            r[3] = v.w;
+        }
+    }
+    const float* myrow = rows + tid * rs;
+    double acc = 0.0;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        __syncthreads();  // previous batch fully consumed (and rows staged, first time round)
+        const uint32_t w0 = batch_off[b], wn = batch_off[b + 1] - w0;
+        for (uint32_t i = tid; i < wn; i += blockDim.x) trees[i] = forest[w0 + i];
+        const uint32_t t_begin = batch_first[b], t_end = batch_first[b + 1];
+        for (uint32_t i = tid; i < t_end - t_begin; i += blockDim.x) {
+            bw[i] = tw[t_begin + i];
+            bmeta[i * 4 + 0] = tree_meta[(t_begin + i) * 3 + 0];
+            bmeta[i * 4 + 1] = tree_meta[(t_begin + i) * 3 + 1];
+            bmeta[i * 4 + 2] = tree_meta[(t_begin + i) * 3 + 2];
+        }
+        __syncthreads();
+        for (uint32_t t0 = t_begin; t0 < t_end; t0 += TI) {
+            uint32_t cur[TI], root[TI], leaftab[TI];
+            uint32_t levels = 0;
+#pragma unroll
+            for (int k = 0; k < TI; k++) {
+                const uint32_t tl = (t0 + k < t_end ? t0 + k : t_end - 1) - t_begin;
+                root[k] = bmeta[tl * 4 + 0];
+                leaftab[k] = bmeta[tl * 4 + 1];
+                cur[k] = root[k];
+                const uint32_t lv = bmeta[tl * 4 + 2];
+                levels = lv > levels ? lv : levels;
+            }
+            for (uint32_t lv = 0; lv < levels; lv++) {
+                // branch-free step so that the TI walks' LDS reads are all in flight together
+                uint64_t word[TI];
+#pragma unroll
+                for (int k = 0; k < TI; k++) word[k] = trees[cur[k]];
+                float xv[TI];
+#pragma unroll
+                for (int k = 0; k < TI; k++) {
+                    const uint32_t fid = (uint32_t)(word[k] >> 32) & 0xFFFFu;
+                    xv[k] = myrow[fid < d ? fid : 0u];
+                }
+#pragma unroll
+                for (int k = 0; k < TI; k++) {
+                    const uint32_t hi = (uint32_t)(word[k] >> 32);
+                    const uint32_t fid = hi & 0xFFFFu;
+                    const float thr = __uint_as_float((uint32_t)word[k]);
+                    const float x = fid < d ? xv[k] : 0.0f;  // Features::get -> None -> 0.0
+                    const uint32_t left = root[k] + (hi >> 16);  // children relative to the root word
+                    const uint32_t next = (x <= thr) ? left : left + 1;
+                    cur[k] = (fid == 0xFFFFu) ? cur[k] : next;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TI; k++) {
+                if (t0 + k < t_end) {
+                    const uint32_t t = t0 + k;
+                    const uint64_t word = trees[cur[k]];
+                    const uint32_t leaf = (uint32_t)(word >> 48);
+                    const double val = __longlong_as_double((long long)trees[leaftab[k] + leaf]);
+                    if (raw_single) {
+                        acc = val;
+                    } else {
+                        double prod = bw[t - t_begin] * val;
+                        acc = acc + prod;
+                    }
                 }
             }
         }
@@ -733,6 +847,8 @@ struct DeviceDataset::Impl {
     DevBuf<TreeNodeDev> nodes;
     DevBuf<int32_t> roots;
     DevBuf<double> tweights;
+    DevBuf<uint64_t> forest;
+    DevBuf<uint32_t> batch_off, batch_first, tree_meta;
     size_t scores_slots = 0;
     size_t last_ldm = 0, last_cols = 0;
     int host_flags = 0;
@@ -1015,12 +1131,129 @@ bool DeviceDataset::score_single_feature(uint32_t fid, double dir, std::string* 
     return true;
 }
 
+// Largest f32 <= split: (f64(x) <= split) <=> (x <= thr) for every non-NaN f32 x.
+static float floor_to_f32(double split) {
+    float t = (float)split;
+    if ((double)t > split) t = std::nextafterf(t, -std::numeric_limits<float>::infinity());
+    return t;
+}
+
+// Packs the forest for tree_ensemble_lds_kernel and launches it.  Returns false with an empty
+// *err when the forest does not fit the compact encoding (caller falls back to the L2 walk).
+bool DeviceDataset::try_score_trees_lds(const FlatTrees& t, std::string* err) {
+    Impl& m = *impl_;
+    if (err) err->clear();
+    const size_t nt = t.root.size();
+    if (nt == 0 || m.d >= 0xFFFF) return false;
+    const size_t row_floats = m.dq * 4 + 1;
+    unsigned bs = 0;
+    const size_t lds_cap = 160 * 1024;
+    size_t tree_bytes_cap = 0;
+    for (unsigned cand : {256u, 128u, 64u}) {
+        size_t rows_b = (size_t)cand * row_floats * sizeof(float);
+        if (rows_b + 8 * 1024 + LDS_TREES_PER_BATCH * 24 <= lds_cap) {
+            bs = cand;
+            tree_bytes_cap = std::min<size_t>(24 * 1024, (lds_cap - rows_b - LDS_TREES_PER_BATCH * 24) / 16 * 16);
+            break;
+        }
+    }
+    if (bs == 0) return false;
+    const size_t words_cap = tree_bytes_cap / 8;
+    struct Packed {
+        std::vector<uint64_t> words;  // node words followed by the f64 leaf table
+        uint32_t nodes = 0, levels = 0;
+    };
+    std::vector<Packed> packed(nt);
+    for (size_t k = 0; k < nt; k++) {
+        Packed& pk = packed[k];
+        std::vector<uint64_t> nodes;
+        std::vector<double> leaves;
+        struct Item { int32_t src; uint32_t dst; uint32_t depth; };
+        std::vector<Item> work;
+        nodes.push_back(0);
+        work.push_back({t.root[k], 0u, 0u});
+        while (!work.empty()) {
+            Item it = work.back();
+            work.pop_back();
+            pk.levels = std::max(pk.levels, it.depth);
+            if (t.fid[it.src] < 0) {
+                if (leaves.size() >= 0xFFFF) return false;
+                uint64_t word = ((uint64_t)leaves.size() << 48) | ((uint64_t)0xFFFFu << 32);
+                nodes[it.dst] = word;
+                leaves.push_back(t.split[it.src]);
+            } else {
+                if (nodes.size() + 2 > 0xFFFF || (uint32_t)t.fid[it.src] >= 0xFFFFu) return false;
+                uint32_t left = (uint32_t)nodes.size();
+                float thr = floor_to_f32(t.split[it.src]);
+                uint32_t tb;
+                std::memcpy(&tb, &thr, 4);
+                nodes[it.dst] = ((uint64_t)left << 48) | ((uint64_t)(uint32_t)t.fid[it.src] << 32) | tb;
+                nodes.push_back(0);
+                nodes.push_back(0);
+                work.push_back({t.lhs[it.src], left, it.depth + 1});
+                work.push_back({t.rhs[it.src], left + 1, it.depth + 1});
+            }
+        }
+        pk.nodes = (uint32_t)nodes.size();
+        pk.words = nodes;
+        for (double v : leaves) {
+            uint64_t bits;
+            std::memcpy(&bits, &v, 8);
+            pk.words.push_back(bits);
+        }
+        if (pk.words.size() > words_cap) return false;
+    }
+    std::vector<uint64_t> forest;
+    std::vector<uint32_t> batch_off(1, 0), batch_first(1, 0), meta(nt * 3);
+    size_t cur_words = 0;
+    for (size_t k = 0; k < nt; k++) {
+        if (cur_words + packed[k].words.size() > words_cap || k - batch_first.back() >= LDS_TREES_PER_BATCH) {
+            batch_off.push_back((uint32_t)forest.size());
+            batch_first.push_back((uint32_t)k);
+            cur_words = 0;
+        }
+        meta[k * 3 + 0] = (uint32_t)cur_words;
+        meta[k * 3 + 1] = (uint32_t)(cur_words + packed[k].nodes);
+        meta[k * 3 + 2] = packed[k].levels;
+        forest.insert(forest.end(), packed[k].words.begin(), packed[k].words.end());
+        cur_words += packed[k].words.size();
+    }
+    batch_off.push_back((uint32_t)forest.size());
+    batch_first.push_back((uint32_t)nt);
+    const size_t nbatch = batch_off.size() - 1;
+    std::vector<double> tw = t.weight;
+    tw.resize(nt, 1.0);
+    if (!m.forest.ensure(forest.size(), err) || !m.batch_off.ensure(batch_off.size(), err) ||
+        !m.batch_first.ensure(batch_first.size(), err) || !m.tree_meta.ensure(meta.size(), err) ||
+        !m.tweights.ensure(nt, err))
+        return false;
+    FR_HIP(hipMemcpyAsync(m.forest.p, forest.data(), forest.size() * 8, hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipMemcpyAsync(m.batch_off.p, batch_off.data(), batch_off.size() * 4, hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipMemcpyAsync(m.batch_first.p, batch_first.data(), batch_first.size() * 4, hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipMemcpyAsync(m.tree_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipMemcpyAsync(m.tweights.p, tw.data(), nt * sizeof(double), hipMemcpyHostToDevice, m.stream));
+    FR_HIP(hipStreamSynchronize(m.stream));
+    const size_t lds = words_cap * 8 + LDS_TREES_PER_BATCH * 24 + (size_t)bs * row_floats * sizeof(float);
+    {
+        ProfScope ps("tree_ensemble_kernel", m.stream);
+        FR_HIP(hipFuncSetAttribute((const void*)tree_ensemble_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        tree_ensemble_lds_kernel<8><<<grid1d(m.np, bs), bs, lds, m.stream>>>(
+            m.xb.p, (uint32_t)m.np, (uint32_t)m.dq, (uint32_t)m.d, m.forest.p, m.batch_off.p, m.tree_meta.p,
+            m.batch_first.p, m.tweights.p, (uint32_t)nbatch, t.raw_single ? 1 : 0, (uint32_t)words_cap, m.scores.p);
+    }
+    FR_HIP(hipGetLastError());
+    return true;
+}
+
 bool DeviceDataset::score_trees(const FlatTrees& t, std::string* err) {
     Impl& m = *impl_;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.bind(err)) return false;
     if (!m.scores.ensure(m.np, err)) return false;
     m.scores_slots = 1;
+    if (try_score_trees_lds(t, err)) return true;
+    if (err && !err->empty()) return false;
     const size_t nt = t.root.size();
     // re-lay the forest out so that the two children of a node are adjacent (rhs = lhs + 1)
     std::vector<TreeNodeDev> nodes;

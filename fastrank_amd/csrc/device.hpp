@@ -105,6 +105,7 @@ class DeviceDataset {
 
   private:
     DeviceDataset();
+    bool try_score_trees_lds(const FlatTrees& trees, std::string* err);
     struct Impl;
     Impl* impl_;
 };
