@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--restarts-per-gpu", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("FR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only for single-GPU smoke tests of the N>1 path")
     args = ap.parse_args()
 
     import torch
@@ -130,16 +132,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # FR_BENCH_DEVICE pins every rank to one ordinal (2-rank smoke test of the N>1 path on a 1-GPU box)
+    dev_ordinal = int(os.environ.get("FR_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_ordinal)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_ordinal))
+        else:
+            dist.init_process_group(backend="gloo")
+    coll_dev = torch.device("cuda", dev_ordinal) if args.backend == "nccl" else torch.device("cpu")
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
 
     import fastrank_amd as fr
     from fastrank_amd import native
 
-    native.set_device(local_rank)
+    native.set_device(dev_ordinal)
     n, d, q, seed = SHAPES[args.shape]
     t0 = time.perf_counter()
     X, y, qid = gen_mslr_shaped(seed, n, d, q)
@@ -181,7 +189,7 @@ def main():
 
     useful = s1["useful_evals"] - s0["useful_evals"]
     raw = s1["raw_evals"] - s0["raw_evals"]
-    tvals = torch.tensor([elapsed, float(useful), float(raw)], dtype=torch.float64, device="cuda")
+    tvals = torch.tensor([elapsed, float(useful), float(raw)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = tvals.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -197,7 +205,7 @@ def main():
     mine = st["restarts"]
     if world > 1:
         dim = d
-        buf = torch.zeros((args.restarts_per_gpu + 1, 3 + dim), dtype=torch.float64, device="cuda")
+        buf = torch.zeros((args.restarts_per_gpu + 1, 3 + dim), dtype=torch.float64, device=coll_dev)
         for k, r in enumerate(mine):
             buf[k, 0], buf[k, 1], buf[k, 2] = 1.0, float(r["restart_id"]), r["score"]
             buf[k, 3:3 + len(r["weights"])] = torch.tensor(r["weights"], dtype=torch.float64)
