@@ -429,11 +429,12 @@ __global__ __launch_bounds__(256) void metric_sort_kernel(
     const uint32_t* __restrict__ qlen, const uint32_t* __restrict__ qtight, const double* __restrict__ gexp,
     const float* __restrict__ gain, const double* __restrict__ disc, const double* __restrict__ norms, int measure,
     int depth, uint32_t B, double* __restrict__ M, uint32_t* __restrict__ rank_out, const uint32_t* __restrict__ perm,
-    int* __restrict__ flags, uint32_t npad_max) {
+    int* __restrict__ flags, uint32_t npad_max, const uint32_t* __restrict__ qlist) {
     extern __shared__ double lds_raw[];
     double* keys = lds_raw;
     uint32_t* idx = (uint32_t*)(keys + npad_max);
-    const uint32_t q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    // queries are launched per size class so that the LDS footprint matches the query length
+    const uint32_t q = qlist[blockIdx.x], b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t base = qstart[q], n = qlen[q];
     uint32_t npad = 1;
     while (npad < n) npad <<= 1;
@@ -496,20 +497,11 @@ __global__ __launch_bounds__(256) void metric_sort_kernel(
         __syncthreads();
         if (tid == 0) {
             if (measure == M_AP) {
-                // src/evaluators.rs:422-447
-                uint32_t num_rel = (uint32_t)norms[q];
-                if (num_rel == 0)
-                    for (uint32_t i = 0; i < n; i++) num_rel += keys[i] != 0.0;
-                if (num_rel != 0) {
-                    int recall_points = 0;
-                    double sum_precision = 0.0;
-                    for (uint32_t i = 0; i < n; i++) {
-                        if (keys[i] != 0.0) {
-                            recall_points += 1;
-                            sum_precision += (double)recall_points / (double)(i + 1);
-                        }
-                    }
-                    result = sum_precision / (double)num_rel;
+                // src/evaluators.rs:422-447, step 1: recall_points at every relevant rank
+                uint32_t c = 0;
+                for (uint32_t i = 0; i < n; i++) {
+                    c += keys[i] != 0.0;
+                    idx[i] = keys[i] != 0.0 ? c : 0u;
                 }
             } else {
                 // src/evaluators.rs:239-252
@@ -519,6 +511,27 @@ __global__ __launch_bounds__(256) void metric_sort_kernel(
                         break;
                     }
                 }
+            }
+        }
+        if (measure == M_AP) {
+            __syncthreads();
+            // step 2 (all threads): precision at each relevant rank, the reference's operands exactly
+            for (uint32_t i = tid; i < n; i += nt)
+                if (idx[i]) keys[i] = (double)(int)idx[i] / (double)(i + 1);
+            __syncthreads();
+            if (tid == 0) {
+                // step 3: ordered sum in rank order, then / num_relevant
+                uint32_t num_rel = (uint32_t)norms[q];
+                uint32_t in_list = 0;
+                double sum_precision = 0.0;
+                for (uint32_t i = 0; i < n; i++) {
+                    if (idx[i]) {
+                        sum_precision += keys[i];
+                        in_list++;
+                    }
+                }
+                if (num_rel == 0) num_rel = in_list;
+                if (num_rel != 0) result = sum_precision / (double)num_rel;
             }
         }
     }
@@ -837,7 +850,11 @@ struct DeviceDataset::Impl {
     std::vector<uint32_t> perm_host;   // [np] original instance id or IDX_INVALID (padding)
     DevBuf<float> xb, gain;
     DevBuf<double> gexp, disc;
-    DevBuf<uint32_t> qstart, qlen, qtight, perm, rank, run_q0, run_q1, run_pos, run_docs, run_order, gcls;
+    DevBuf<uint32_t> qstart, qlen, qtight, perm, rank, run_q0, run_q1, run_pos, run_docs, run_order, gcls, qlist;
+    struct SizeClass {
+        uint32_t npad, offset, count;
+    };
+    std::vector<SizeClass> size_classes;  // queries bucketed by next power of two of their length
     DevBuf<double> dcgtab;
     DevBuf<int> flags;
     DevBuf<unsigned long long> dbgc;
@@ -969,6 +986,25 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
     // longest-first schedule so the biggest runs do not form the tail of a launch
     std::stable_sort(run_order.begin(), run_order.end(), [&](uint32_t x, uint32_t y) { return run_docs[x] > run_docs[y]; });
 
+    // ---- size classes for the general (sort) evaluator: LDS sized per class, not per dataset maximum
+    std::vector<uint32_t> qlist(m.nq);
+    {
+        auto npad_of = [](uint32_t len) {
+            uint32_t p2 = 64;
+            while (p2 < len) p2 <<= 1;
+            return p2;
+        };
+        for (size_t q = 0; q < m.nq; q++) qlist[q] = (uint32_t)q;
+        std::stable_sort(qlist.begin(), qlist.end(), [&](uint32_t x, uint32_t y) { return npad_of(qlen[x]) < npad_of(qlen[y]); });
+        for (size_t k = 0; k < m.nq;) {
+            uint32_t np2 = npad_of(qlen[qlist[k]]);
+            size_t e = k;
+            while (e < m.nq && npad_of(qlen[qlist[e]]) == np2) e++;
+            m.size_classes.push_back({np2, (uint32_t)k, (uint32_t)(e - k)});
+            k = e;
+        }
+    }
+
     // ---- padded per-position arrays ------------------------------------------------------------
     m.perm_host.assign(m.np, IDX_INVALID);
     std::vector<float> gain(m.np, 0.0f);
@@ -1058,7 +1094,8 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
             !upload(m.qstart, qstart, err) || !upload(m.qlen, qlen, err) || !upload(m.qtight, qtight, err) ||
             !upload(m.perm, m.perm_host, err) || !upload(m.run_q0, run_q0, err) || !upload(m.run_q1, run_q1, err) ||
             !upload(m.run_pos, run_pos, err) || !upload(m.run_docs, run_docs, err) ||
-            !upload(m.run_order, run_order, err) || !upload(m.gcls, gcls, err) || !upload(m.dcgtab, dcgtab, err))
+            !upload(m.run_order, run_order, err) || !upload(m.gcls, gcls, err) || !upload(m.dcgtab, dcgtab, err) ||
+            !upload(m.qlist, qlist, err))
             return nullptr;
         if (!m.flags.ensure(1, err) || !m.dbgc.ensure(4, err)) return nullptr;
         if (!chk(hipMemset(m.flags.p, 0, sizeof(int)), "clear flags")) return nullptr;
@@ -1386,12 +1423,16 @@ bool DeviceDataset::metric_from_scores(int measure, int64_t depth, const double*
     int dd = depth < 0 ? -1 : (depth > 0x7fffffff ? 0x7fffffff : (int)depth);
     {
         ProfScope ps("metric_sort_kernel", m.stream);
-        dim3 grid((unsigned)m.nq, (unsigned)B);
-        unsigned bs = npad >= 512 ? 256 : 64;
-        metric_sort_kernel<<<grid, bs, lds, m.stream>>>(m.scores.p, (uint32_t)m.np, m.qstart.p, m.qlen.p, m.qtight.p,
-                                                        m.gexp.p, m.gain.p, m.disc.p, m.norms.p, measure, dd, (uint32_t)B,
-                                                        m.M.p, want_rank ? m.rank.p : nullptr, m.perm.p, m.flags.p,
-                                                        (uint32_t)npad);
+        for (const auto& sc : m.size_classes) {
+            const size_t cls_lds = (size_t)sc.npad * (sizeof(double) + sizeof(uint32_t));
+            dim3 grid((unsigned)sc.count, (unsigned)B);
+            unsigned bs = sc.npad >= 512 ? 256 : 64;
+            metric_sort_kernel<<<grid, bs, cls_lds, m.stream>>>(m.scores.p, (uint32_t)m.np, m.qstart.p, m.qlen.p,
+                                                                m.qtight.p, m.gexp.p, m.gain.p, m.disc.p, m.norms.p,
+                                                                measure, dd, (uint32_t)B, m.M.p,
+                                                                want_rank ? m.rank.p : nullptr, m.perm.p, m.flags.p,
+                                                                sc.npad, m.qlist.p + sc.offset);
+        }
     }
     FR_HIP(hipGetLastError());
     m.last_ldm = B;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""End-to-end train_model to convergence on a synthetic MSLR shape (BASELINE.json configs[1]):
+wall time, ticks, useful/raw evaluations, final NDCG@10."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import fastrank_amd as fr  # noqa: E402
+from fastrank_amd import native  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="10k")
+    ap.add_argument("--restarts", type=int, default=8)
+    ap.add_argument("--measure", default="ndcg@10")
+    ap.add_argument("--max-ticks", type=int, default=100000)
+    args = ap.parse_args()
+    n, d, q, seed = bench.SHAPES[args.shape]
+    X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
+    ds = fr.CDataset.from_numpy(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = args.measure
+    p = req.params
+    p.num_restarts, p.seed, p.quiet = args.restarts, 42, True
+    t0 = time.perf_counter()
+    run = native.CoordinateAscentRun(ds, req)
+    t_init = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ticks = 0
+    while not run.finished and ticks < args.max_ticks:
+        ticks += run.step(136)
+        st = run.state()
+        print("  ticks=%d best=%.6f useful=%d raw=%d elapsed=%.1fs" % (
+            ticks, max(r["score"] for r in st["restarts"]), st["stats"]["useful_evals"], st["stats"]["raw_evals"],
+            time.perf_counter() - t0), flush=True)
+    wall = time.perf_counter() - t0
+    st = run.state()
+    model = native.select_model(st["restarts"], False)
+    mean = float(np.mean(native.evaluate_dense(model, ds, args.measure)[1]))
+    print(json.dumps({"shape": args.shape, "restarts": args.restarts, "measure": args.measure, "finished": run.finished,
+                      "ticks": ticks, "train_wall_s": wall, "upload_init_s": t_init,
+                      "useful_evals": st["stats"]["useful_evals"], "raw_evals": st["stats"]["raw_evals"],
+                      "useful_evals_per_s": st["stats"]["useful_evals"] / wall, "final_mean": mean,
+                      "path": st["stats"]["path"]}))
+
+
+if __name__ == "__main__":
+    main()
