@@ -812,7 +812,9 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
         for (size_t g = 0; g < n_groups; g++)
             if (n_cand[g] == 0 || n_cand[g] > 64 || features[g] >= d)
                 fr::fail_str("fr_evaluate_candidates: malformed group");
-        if (dev.linesearch_supported(ev.measure, ev.depth)) {
+        const bool topk = dev.linesearch_supported(ev.measure, ev.depth);
+        const bool full = !topk && dev.fullrank_supported(ev.measure, ev.depth) && !getenv("FR_FORCE_GENERIC");
+        if (topk || full) {
             std::vector<frdev::LineGroup> groups(n_groups);
             for (size_t g = 0; g < n_groups; g++) {
                 groups[g].feature = features[g];
@@ -820,7 +822,11 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
                 groups[g].candidates.assign(candidates + g * 64, candidates + g * 64 + n_cand[g]);
             }
             std::vector<double> means;
-            if (!dev.linesearch_ndcg(ev.depth, ev.norms.data(), groups, &means, &err)) fr::fail_str(err);
+            if (topk) {
+                if (!dev.linesearch_ndcg(ev.depth, ev.norms.data(), groups, &means, &err)) fr::fail_str(err);
+            } else {
+                if (!dev.linesearch_fullrank(ev.measure, ev.depth, ev.norms.data(), groups, &means, &err)) fr::fail_str(err);
+            }
             fr::check_flags(dev);
             std::copy(means.begin(), means.end(), out_means);
             if (out_per_query) {
@@ -839,7 +845,7 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
                     w[off + features[g]] = candidates[g * 64 + c];
                     slot.push_back(g * 64 + c);
                 }
-            if (out_per_query) fr::fail_str("fr_evaluate_candidates: per-query output needs an ndcg@k (k<=20) measure");
+            if (out_per_query) fr::fail_str("fr_evaluate_candidates: per-query output is not available on the general sort path");
             std::vector<double> means;
             fr::evaluate_means_generic(view, ev, w, slot.size(), means);
             for (size_t g = 0; g < n_groups * 64; g++) out_means[g] = 0.0;

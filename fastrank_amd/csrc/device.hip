@@ -839,6 +839,262 @@ __global__ __launch_bounds__(WAVE, LS_WAVES_PER_SIMD) void linesearch_ndcg_kerne
 }
 
 // ----------------------------------------------------------------------------------------------
+// Full-ranking line search (AP / RR / NDCG without depth or with depth > 20): two kernels per
+// chunk of line groups.  Kernel A scores every candidate exactly like phase S above and writes one
+// 512-byte row per (document, group): rows[(p * GC + gl) * 64 + c].  Kernel B (lane = candidate)
+// ranks the documents that can contribute to the metric by counting, for each of them, the
+// documents that precede it in the reference order, then walks the ranks in order.
+// ----------------------------------------------------------------------------------------------
+
+struct FSArgs {
+    const float4* xb;
+    const uint32_t* run_pos;
+    const uint32_t* run_docs;
+    const uint32_t* run_order;
+    const uint32_t* gfeat;   // [GC]
+    const double* gw;        // [GC][4*dq]
+    const double* gcand;     // [GC][64]
+    double* rows;            // [np][GC][64]
+    int* flags;
+    uint32_t dq, d, nruns, GC;
+};
+
+template <int CT, int RB>
+__global__ __launch_bounds__(WAVE, LS_WAVES_PER_SIMD) void linesearch_scores_kernel(FSArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double wdyn[];  // wpre[4*dq], wsuf[4*dq]
+    __shared__ double tr[RB * LS_ROWPAD];
+    __shared__ double cwl[WAVE];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t xcd = blk & 7u, seq = blk >> 3;
+    const uint32_t g = seq % a.GC;
+    const uint32_t ri = (seq / a.GC) * 8u + xcd;
+    if (ri >= a.nruns) return;
+    const uint32_t r = a.run_order[ri];
+    const uint32_t pos = a.run_pos[r];
+    const uint32_t run_end = pos + a.run_docs[r];
+    const uint32_t f = a.gfeat[g];
+    const uint32_t dq = a.dq, dp = a.dq * 4, d = a.d;
+    const double* __restrict__ w = a.gw + (size_t)g * dp;
+    double* wpre = wdyn;
+    double* wsuf = wdyn + dp;
+    for (uint32_t j = lane; j < dp; j += WAVE) {
+        const double wv = j < d ? w[j] : 0.0;
+        wpre[j] = j < f ? wv : 0.0;
+        wsuf[j] = j > f ? wv : 0.0;
+    }
+    cwl[lane] = a.gcand[(size_t)g * 64 + lane];
+    __syncthreads();
+    bool nan_seen = false;
+    const uint32_t ngp = (f + 3) >> 2;
+    const uint32_t sq0 = (f + 1) >> 2;
+    const uint32_t fgrp = f >> 2, fsub = f & 3;
+    for (uint32_t pb = pos; pb < run_end; pb += WAVE) {
+        const float4* __restrict__ tile = a.xb + (size_t)(pb >> 6) * dq * 64 + lane;
+        double P = 0.0;
+        for (uint32_t j4 = 0; j4 < ngp; j4++) {
+            const float4 x = tile[(size_t)j4 * 64];
+            const double* wp = wpre + j4 * 4;
+            double p0 = (double)x.x * wp[0];
+            P = P + p0;
+            double p1 = (double)x.y * wp[1];
+            P = P + p1;
+            double p2 = (double)x.z * wp[2];
+            P = P + p2;
+            double p3 = (double)x.w * wp[3];
+            P = P + p3;
+        }
+        const double xf = (double)((const float*)(tile + (size_t)fgrp * 64))[fsub];
+        float4 x0 = tile[(size_t)(sq0 < dq ? sq0 : dq - 1) * 64];
+        double sc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            double prod = xf * cwl[c];
+            sc[c] = P + prod;
+        }
+        for (uint32_t j4 = sq0; j4 < dq; j4++) {
+            const float4 x2 = tile[(size_t)(j4 + 1 < dq ? j4 + 1 : dq - 1) * 64];
+            const double* wp = wsuf + j4 * 4;
+            const float xs[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                double prod = (double)xs[u] * wp[u];
+#pragma unroll
+                for (int c = 0; c < CT; c++) sc[c] = sc[c] + prod;
+            }
+            x0 = x2;
+        }
+        // transpose RB rows at a time and store them as coalesced 512-byte rows
+        const uint32_t nvalid = (run_end - pb) < (uint32_t)WAVE ? (run_end - pb) : (uint32_t)WAVE;
+        for (uint32_t b0 = 0; b0 < nvalid; b0 += RB) {
+            if (lane >= b0 && lane < b0 + RB) {
+                double* row = tr + (lane - b0) * LS_ROWPAD;
+#pragma unroll
+                for (int c = 0; c < CT; c++) row[c] = sc[c];
+            }
+            __syncthreads();
+            const uint32_t nb = (nvalid - b0) < (uint32_t)RB ? (nvalid - b0) : (uint32_t)RB;
+            for (uint32_t rr = 0; rr < nb; rr++) {
+                const double e = lane < (uint32_t)CT ? tr[rr * LS_ROWPAD + lane] : 0.0;
+                nan_seen |= (e != e);
+                a.rows[((size_t)(pb + b0 + rr) * a.GC + g) * 64 + lane] = e;
+            }
+            __syncthreads();
+        }
+    }
+    if (nan_seen) atomicOr(a.flags, FLAG_NAN_SCORE);
+}
+
+struct RMArgs {
+    const double* rows;        // [np][GC][64]
+    const uint32_t* qstart;
+    const uint32_t* qlen;
+    const uint32_t* qnpos;     // [nq] documents with gain > 0 (a prefix of the query: gain-descending layout)
+    const uint32_t* qnneg;     // [nq] documents with gain < 0 (a suffix)
+    const uint32_t* gcls;      // [np]
+    const double* termtab;     // [ncls][tablen]: (2^gain - 1) / log2(rank + 2)
+    const double* norms;
+    const uint32_t* gncand;    // [GC]
+    const uint32_t* qlist;     // queries of this size class
+    double* M;                 // [nq][ldm]
+    int* flags;
+    uint32_t GC, ldm, col0, tablen;
+    int measure, depth;
+};
+
+constexpr int RM_AB = 32;  // documents ranked per sweep over the query
+constexpr int RM_PF = 8;   // rows loaded together while sweeping
+
+// One wave per (query, group), lane = candidate.  For each block of RM_AB "interesting" documents
+// (relevant ones for AP/RR, non-zero-gain ones for NDCG) the wave sweeps every document row of the
+// query once and counts, per lane, how many documents precede each of the RM_AB in the reference
+// order (score desc; ties: later position first = gain asc, id asc; src/evaluators.rs:34-49).
+// Ranks are then scattered into a per-lane rank table in LDS and consumed in rank order, so the
+// floating-point sums are formed exactly like the reference forms them.
+__global__ __launch_bounds__(512) void rank_metric_kernel(RMArgs a) {
+    extern __shared__ unsigned char at_rank[];  // [npad][64] class id (NDCG) or relevance flag (AP)
+    __shared__ uint32_t best_shared[WAVE];
+    // long queries get several waves per block: the waves split the blocks of documents to rank and
+    // share the per-lane rank table; wave 0 then walks the ranks
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t q = a.qlist[blockIdx.x];
+    const uint32_t g = blockIdx.y;
+    const uint32_t base = a.qstart[q], n = a.qlen[q];
+    const uint32_t npos = a.qnpos[q], nneg = a.qnneg[q];
+    const uint32_t ncand = a.gncand[g];
+    const size_t rstride = (size_t)a.GC * 64;
+    const double* __restrict__ rows = a.rows + ((size_t)base * a.GC + g) * 64 + lane;
+    const bool ndcg = a.measure == M_NDCG;
+    // documents whose rank matters: [0, npos) and, for NDCG, also [n - nneg, n)
+    const uint32_t ninteresting = npos + (ndcg ? nneg : 0u);
+    for (uint32_t r = wave; r < n; r += nwaves) at_rank[r * 64 + lane] = 0xFF;
+    if (wave == 0) best_shared[lane] = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t best_rank = 0xFFFFFFFFu;  // RR: rank of the best relevant document
+    for (uint32_t a0 = wave * RM_AB; a0 < ninteresting; a0 += nwaves * RM_AB) {
+        double sa[RM_AB];
+        uint32_t cnt[RM_AB], apos[RM_AB];
+#pragma unroll
+        for (int t = 0; t < RM_AB; t++) {
+            uint32_t ai = a0 + t < ninteresting ? a0 + t : ninteresting - 1;
+            apos[t] = ai < npos ? ai : (n - nneg) + (ai - npos);
+            sa[t] = rows[(size_t)apos[t] * rstride];
+            cnt[t] = 0;
+        }
+        const uint32_t amin = apos[0], amax = apos[RM_AB - 1];
+        // Sweep the query's rows RM_PF at a time (independent loads in flight).  Documents stored
+        // before the block precede a only if s_k > s_a (a later document wins ties); documents stored
+        // after it also win ties (s_k >= s_a); inside the block's position range the rule is per pair.
+        for (uint32_t k0 = 0; k0 < n; k0 += RM_PF) {
+            double sk[RM_PF];
+#pragma unroll
+            for (int u = 0; u < RM_PF; u++) sk[u] = rows[(size_t)(k0 + u < n ? k0 + u : n - 1) * rstride];
+            if (k0 + RM_PF <= amin) {
+#pragma unroll
+                for (int u = 0; u < RM_PF; u++)
+#pragma unroll
+                    for (int t = 0; t < RM_AB; t++) cnt[t] += (sk[u] > sa[t]) ? 1u : 0u;
+            } else if (k0 > amax && k0 + RM_PF <= n) {
+#pragma unroll
+                for (int u = 0; u < RM_PF; u++)
+#pragma unroll
+                    for (int t = 0; t < RM_AB; t++) cnt[t] += (sk[u] >= sa[t]) ? 1u : 0u;
+            } else {
+#pragma unroll
+                for (int u = 0; u < RM_PF; u++) {
+                    const uint32_t k = k0 + u;
+                    if (k < n) {
+#pragma unroll
+                        for (int t = 0; t < RM_AB; t++) {
+                            const bool before =
+                                (k > apos[t]) ? (sk[u] >= sa[t]) : ((k < apos[t]) ? (sk[u] > sa[t]) : false);
+                            cnt[t] += before ? 1u : 0u;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RM_AB; t++) {
+            if (a0 + t < ninteresting) {
+                if (ndcg) {
+                    at_rank[cnt[t] * 64 + lane] = (unsigned char)a.gcls[base + apos[t]];
+                } else {
+                    at_rank[cnt[t] * 64 + lane] = 1;
+                    best_rank = cnt[t] < best_rank ? cnt[t] : best_rank;
+                }
+            }
+        }
+    }
+    if (!ndcg && a.measure != M_AP && best_rank != 0xFFFFFFFFu) atomicMin(&best_shared[lane], best_rank);
+    __syncthreads();
+    if (wave != 0) return;
+    best_rank = best_shared[lane];
+    double val = 0.0;
+    int fl = 0;
+    if (ndcg) {
+        // src/evaluators.rs:255-272,350-380: terms in rank order from 0.0; zero-gain ranks add +0.0 (skipped)
+        const uint32_t L = a.depth >= 0 ? ((uint32_t)a.depth < n ? (uint32_t)a.depth : n) : n;
+        double dcg = 0.0;
+        for (uint32_t r = 0; r < L; r++) {
+            const uint32_t c = at_rank[r * 64 + lane];
+            if (c != 0xFF) {
+                double term = a.termtab[(size_t)c * a.tablen + r];
+                dcg = dcg + term;
+            }
+        }
+        const double norm = a.norms[q];
+        if (norm == norm) {
+            if (dcg > norm) fl |= FLAG_ACTUAL_GT_IDEAL;
+            val = dcg / norm;
+        }
+    } else if (a.measure == M_AP) {
+        // src/evaluators.rs:422-447
+        uint32_t num_rel = (uint32_t)a.norms[q];
+        if (num_rel == 0) num_rel = npos;
+        if (num_rel != 0) {
+            int recall_points = 0;
+            double sum_precision = 0.0;
+            for (uint32_t r = 0; r < n; r++) {
+                if (at_rank[r * 64 + lane] != 0xFF) {
+                    recall_points += 1;
+                    sum_precision += (double)recall_points / (double)(r + 1);
+                }
+            }
+            val = sum_precision / (double)num_rel;
+        }
+    } else {
+        // src/evaluators.rs:239-252
+        if (best_rank != 0xFFFFFFFFu) val = 1.0 / (double)(best_rank + 1);
+    }
+    if (lane < ncand) {
+        if (fl) atomicOr(a.flags, fl);
+        a.M[(size_t)q * a.ldm + a.col0 + (size_t)g * 64 + lane] = val;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // DeviceDataset
 // ----------------------------------------------------------------------------------------------
 
@@ -855,6 +1111,9 @@ struct DeviceDataset::Impl {
         uint32_t npad, offset, count;
     };
     std::vector<SizeClass> size_classes;  // queries bucketed by next power of two of their length
+    DevBuf<uint32_t> qnpos, qnneg;
+    DevBuf<double> termtab, rows;
+    size_t ncls = 0, tablen = 0;
     DevBuf<double> dcgtab;
     DevBuf<int> flags;
     DevBuf<unsigned long long> dbgc;
@@ -1046,6 +1305,28 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
                 dcgtab[c * LS_KT + i] = (std::pow(2.0, (double)cls_gain[c]) - 1.0) / std::log2((double)i + 2.0);
     }
 
+    // per-query counts of positive / negative gains (documents are stored gain-descending, so these are a
+    // prefix / suffix of the query) and the full-depth term table for the rank-counting evaluator
+    std::vector<uint32_t> qnpos(m.nq, 0), qnneg(m.nq, 0);
+    std::vector<double> termtab;
+    {
+        for (size_t q = 0; q < m.nq; q++)
+            for (uint32_t k = 0; k < qlen[q]; k++) {
+                float gv = gain[(size_t)qstart[q] + k];
+                qnpos[q] += gv > 0.0f;
+                qnneg[q] += gv < 0.0f;
+            }
+        m.ncls = dcgtab.size() / LS_KT;
+        m.tablen = std::max<size_t>(m.maxlen, 1);
+        if (m.ncls <= 255 && m.ncls * m.tablen <= (size_t(64) << 20)) {
+            termtab.resize(m.ncls * m.tablen);
+            for (size_t c = 0; c < m.ncls; c++) {
+                const double ge = dcgtab[c * LS_KT] * std::log2(2.0);  // = 2^g - 1 (term at rank 0, log2(2) = 1)
+                for (size_t r = 0; r < m.tablen; r++) termtab[c * m.tablen + r] = ge / std::log2((double)r + 2.0);
+            }
+        }
+    }
+
     // ---- feature tiles: built on the host in slabs (threads over tiles), uploaded slab by slab.
     // One-time cost; SURVEY 8d excludes it from evals/s and bench.py reports it separately.
     const size_t ntiles = m.np / 64;
@@ -1095,7 +1376,8 @@ std::shared_ptr<DeviceDataset> DeviceDataset::create(const HostCSR& csr, std::st
             !upload(m.perm, m.perm_host, err) || !upload(m.run_q0, run_q0, err) || !upload(m.run_q1, run_q1, err) ||
             !upload(m.run_pos, run_pos, err) || !upload(m.run_docs, run_docs, err) ||
             !upload(m.run_order, run_order, err) || !upload(m.gcls, gcls, err) || !upload(m.dcgtab, dcgtab, err) ||
-            !upload(m.qlist, qlist, err))
+            !upload(m.qlist, qlist, err) || !upload(m.qnpos, qnpos, err) || !upload(m.qnneg, qnneg, err) ||
+            !upload(m.termtab, termtab, err))
             return nullptr;
         if (!m.flags.ensure(1, err) || !m.dbgc.ensure(4, err)) return nullptr;
         if (!chk(hipMemset(m.flags.p, 0, sizeof(int)), "clear flags")) return nullptr;
@@ -1603,6 +1885,132 @@ bool DeviceDataset::linesearch_ndcg(int64_t depth, const double* norms, const st
         fprintf(stderr, "[FR_LS_DEBUG] docs=%llu rows=%llu (%.3f of docs) batches=%llu insertion_rows=%llu\n", c[3], c[0],
                 (double)c[0] / (double)c[3], c[1], c[2]);
     }
+    return m.pull_flags(err);
+}
+
+bool DeviceDataset::fullrank_supported(int measure, int64_t depth) const {
+    const Impl& m = *impl_;
+    (void)depth;
+    if (m.nonfinite || m.dq * 4 > 2048) return false;
+    if (m.maxlen > 2048) return false;                       // per-lane rank table must fit LDS (64 B per rank)
+    if (measure == M_NDCG && m.termtab.cap < m.ncls * m.tablen) return false;  // too many gain classes
+    return measure == M_NDCG || measure == M_AP || measure == M_RR;
+}
+
+template <int CT>
+static void launch_scores(const FSArgs& a, unsigned nblocks, size_t lds, hipStream_t st) {
+    linesearch_scores_kernel<CT, 16><<<dim3(nblocks), dim3(WAVE), lds, st>>>(a);
+}
+
+// Full-ranking line search: every candidate of every group, any measure.  means[g*64 + c].
+bool DeviceDataset::linesearch_fullrank(int measure, int64_t depth, const double* norms,
+                                        const std::vector<LineGroup>& groups, std::vector<double>* means,
+                                        std::string* err) {
+    Impl& m = *impl_;
+    std::lock_guard<std::mutex> lk(m.mu);
+    if (!m.bind(err)) return false;
+    if (!fullrank_supported(measure, depth)) {
+        if (err) *err = "linesearch_fullrank: unsupported dataset or measure";
+        return false;
+    }
+    const size_t G = groups.size();
+    means->assign(G * 64, 0.0);
+    if (G == 0) return true;
+    const size_t dp = m.dq * 4;
+    const size_t ldm = G * 64;
+    size_t maxc = 0;
+    for (const auto& lg : groups) {
+        if (lg.feature >= m.d || lg.weights.size() != m.d || lg.candidates.empty() || lg.candidates.size() > 64) {
+            if (err) *err = "linesearch_fullrank: malformed line group";
+            return false;
+        }
+        maxc = std::max(maxc, lg.candidates.size());
+    }
+    // chunk the groups so that the score rows stay within ~8 GiB of HBM
+    const size_t row_bytes = 64 * sizeof(double);
+    size_t GC = std::max<size_t>(1, std::min<size_t>(G, (size_t(8) << 30) / (m.np * row_bytes)));
+    if (!m.M.ensure(m.nq * ldm, err) || !m.norms.ensure(m.nq, err) || !m.rows.ensure(m.np * GC * 64, err) ||
+        !m.gfeat.ensure(GC, err) || !m.gncand.ensure(GC, err) || !m.gw.ensure(GC * dp, err) ||
+        !m.gcand.ensure(GC * 64, err) || !m.means.ensure(ldm, err))
+        return false;
+    FR_HIP(hipMemcpyAsync(m.norms.p, norms, m.nq * sizeof(double), hipMemcpyHostToDevice, m.stream));
+    int dd = depth < 0 ? -1 : (depth > 0x7fffffff ? 0x7fffffff : (int)depth);
+    for (size_t g0 = 0; g0 < G; g0 += GC) {
+        const size_t gc = std::min(GC, G - g0);
+        std::vector<uint32_t> gfeat(gc), gncand(gc);
+        std::vector<double> gw(gc * dp, 0.0), gcand(gc * 64, 0.0);
+        for (size_t g = 0; g < gc; g++) {
+            const LineGroup& lg = groups[g0 + g];
+            gfeat[g] = lg.feature;
+            gncand[g] = (uint32_t)lg.candidates.size();
+            std::memcpy(&gw[g * dp], lg.weights.data(), m.d * sizeof(double));
+            std::memcpy(&gcand[g * 64], lg.candidates.data(), lg.candidates.size() * sizeof(double));
+        }
+        FR_HIP(hipMemcpyAsync(m.gfeat.p, gfeat.data(), gc * sizeof(uint32_t), hipMemcpyHostToDevice, m.stream));
+        FR_HIP(hipMemcpyAsync(m.gncand.p, gncand.data(), gc * sizeof(uint32_t), hipMemcpyHostToDevice, m.stream));
+        FR_HIP(hipMemcpyAsync(m.gw.p, gw.data(), gc * dp * sizeof(double), hipMemcpyHostToDevice, m.stream));
+        FR_HIP(hipMemcpyAsync(m.gcand.p, gcand.data(), gc * 64 * sizeof(double), hipMemcpyHostToDevice, m.stream));
+        FR_HIP(hipStreamSynchronize(m.stream));  // the staging vectors are locals
+        FSArgs fa;
+        fa.xb = (const float4*)m.xb.p;
+        fa.run_pos = m.run_pos.p;
+        fa.run_docs = m.run_docs.p;
+        fa.run_order = m.run_order.p;
+        fa.gfeat = m.gfeat.p;
+        fa.gw = m.gw.p;
+        fa.gcand = m.gcand.p;
+        fa.rows = m.rows.p;
+        fa.flags = m.flags.p;
+        fa.dq = (uint32_t)m.dq;
+        fa.d = (uint32_t)m.d;
+        fa.nruns = (uint32_t)m.nruns;
+        fa.GC = (uint32_t)gc;
+        const size_t nblocks = ((m.nruns + 7) / 8) * 8 * gc;
+        {
+            ProfScope ps("linesearch_scores_kernel", m.stream);
+            const size_t lds = 2 * dp * sizeof(double);
+            if (maxc <= 16) launch_scores<16>(fa, (unsigned)nblocks, lds, m.stream);
+            else if (maxc <= 51) launch_scores<51>(fa, (unsigned)nblocks, lds, m.stream);
+            else launch_scores<64>(fa, (unsigned)nblocks, lds, m.stream);
+        }
+        FR_HIP(hipGetLastError());
+        RMArgs ra;
+        ra.rows = m.rows.p;
+        ra.qstart = m.qstart.p;
+        ra.qlen = m.qlen.p;
+        ra.qnpos = m.qnpos.p;
+        ra.qnneg = m.qnneg.p;
+        ra.gcls = m.gcls.p;
+        ra.termtab = m.termtab.p;
+        ra.norms = m.norms.p;
+        ra.gncand = m.gncand.p;
+        ra.M = m.M.p;
+        ra.flags = m.flags.p;
+        ra.GC = (uint32_t)gc;
+        ra.ldm = (uint32_t)ldm;
+        ra.col0 = (uint32_t)(g0 * 64);
+        ra.tablen = (uint32_t)m.tablen;
+        ra.measure = measure;
+        ra.depth = dd;
+        {
+            ProfScope ps("rank_metric_kernel", m.stream);
+            FR_HIP(hipFuncSetAttribute((const void*)rank_metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       128 * 1024));
+            // longest queries first (their O(n^2) sweeps are the tail), several waves per long query
+            for (size_t ci = m.size_classes.size(); ci-- > 0;) {
+                const auto& sc = m.size_classes[ci];
+                ra.qlist = m.qlist.p + sc.offset;
+                dim3 grid((unsigned)sc.count, (unsigned)gc);
+                const unsigned waves = sc.npad <= 128 ? 1u : (sc.npad <= 256 ? 2u : (sc.npad <= 512 ? 4u : 8u));
+                rank_metric_kernel<<<grid, WAVE * waves, (size_t)sc.npad * 64, m.stream>>>(ra);
+            }
+        }
+        FR_HIP(hipGetLastError());
+    }
+    if (!launch_means(m.M.p, ldm, ldm, m.nq, m.partial, m.means, m.stream, err)) return false;
+    FR_HIP(hipMemcpyAsync(means->data(), m.means.p, ldm * sizeof(double), hipMemcpyDeviceToHost, m.stream));
+    m.last_ldm = ldm;
+    m.last_cols = ldm;
     return m.pull_flags(err);
 }
 

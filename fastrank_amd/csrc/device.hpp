@@ -97,6 +97,10 @@ class DeviceDataset {
     // evaluates every candidate of every group; means[g*64 + c]
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);
+    // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----
+    bool fullrank_supported(int measure, int64_t depth) const;
+    bool linesearch_fullrank(int measure, int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
+                             std::vector<double>* means, std::string* err);
     // column stride of the last linesearch result (for download_per_query-style inspection)
     size_t last_ldm() const;
     bool download_last_matrix(std::vector<double>* out, size_t* ldm, std::string* err);

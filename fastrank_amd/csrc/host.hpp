@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -722,7 +723,8 @@ class CATrainer {
         for (uint32_t r = 0; r < p_.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
         for (uint32_t r = rbegin; r < rend; r++) rs_.emplace_back(r, child[r]);
         fused_ = dev.linesearch_supported(ev_.measure, ev_.depth);
-        stats_.path = fused_ ? "fused_linesearch" : "generic_sort";
+        fullrank_ = !fused_ && dev.fullrank_supported(ev_.measure, ev_.depth) && !getenv("FR_FORCE_GENERIC");
+        stats_.path = fused_ ? "fused_linesearch" : (fullrank_ ? "fused_fullrank" : "generic_sort");
         stats_.restarts = (uint32_t)rs_.size();
         if (rs_.empty()) return;
 
@@ -778,7 +780,7 @@ class CATrainer {
             if (p_.normalize) l1_normalize(r.base);  // entries >= model_dim are 0 and stay 0
             double orig = r.base[f];
             line_candidates(orig, p_, r.cands, r.block_len);
-            if (fused_) {
+            if (fused_ || fullrank_) {
                 r.first_group = groups_.size();
                 for (size_t c0 = 0; c0 < r.cands.size(); c0 += 64) {
                     frdev::LineGroup lg;
@@ -802,11 +804,16 @@ class CATrainer {
             std::string _err;
             if (!dev.linesearch_ndcg(ev_.depth, ev_.norms.data(), groups_, &means_, &_err)) fail_str(_err);
             check_flags(dev);
+        } else if (fullrank_) {
+            std::string _err;
+            if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_, &means_, &_err))
+                fail_str(_err);
+            check_flags(dev);
         } else {
             evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
         }
         stats_.ticks++;
-        stats_.groups += fused_ ? groups_.size() : gen_B;
+        stats_.groups += (fused_ || fullrank_) ? groups_.size() : gen_B;
         for (Restart& r : rs_) {
             if (r.done) continue;
             uint32_t f = r.order[r.pos];
@@ -814,7 +821,8 @@ class CATrainer {
             size_t c = 0;
             for (int s = 0; s < 3; s++) {
                 for (uint32_t it = 0; it < r.block_len[s]; it++, c++) {
-                    double sc = fused_ ? means_[(r.first_group + c / 64) * 64 + (c % 64)] : means_[r.first_group + c];
+                    double sc = (fused_ || fullrank_) ? means_[(r.first_group + c / 64) * 64 + (c % 64)]
+                                                      : means_[r.first_group + c];
                     stats_.useful_evals++;
                     if (sc == sc && sc > r.best_score) {  // core.rs:57-66: NaN rejected, strict >
                         r.best_score = sc;
@@ -881,6 +889,7 @@ class CATrainer {
     size_t d_ = 0;
     uint32_t model_dim_ = 0;
     bool fused_ = false;
+    bool fullrank_ = false;
     std::vector<Restart> rs_;
     std::vector<frdev::LineGroup> groups_;
     std::vector<double> gen_w_, means_;

@@ -404,7 +404,7 @@ def test_model_serialization_keeps_map(trec):
     scores = model.predict_scores(g)
     assert 0 in scores and len(scores) - 1 in scores and len(scores) == len(y)
     stats = native.last_train_stats()
-    assert stats["path"] == "fused_linesearch" or stats["path"] == "generic_sort"
+    assert stats["path"] in ("fused_linesearch", "fused_fullrank", "generic_sort")
     assert stats["useful_evals"] <= stats["raw_evals"] and stats["ticks"] > 0
 
 
@@ -546,3 +546,53 @@ def test_ranksvm_file_and_numpy_entry_points_train_identically(trec, known):
         assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
     sparse = fr.CModel.from_dict(a).predict_scores(part)
     assert len(sparse) == part.num_instances() == int(mask.sum())
+
+
+@pytest.mark.parametrize("measure", ["map", "mrr", "ndcg", "ndcg@50"])
+def test_fullrank_line_search_matches_oracle_and_general_path(measure):
+    """AP / RR / depth-less NDCG line search: scores kernel + rank-counting kernel, against the
+    oracle per query and against the independent sort-based path (FR_FORCE_GENERIC)."""
+    X, y, qid = synth_dataset(53, 5000, 20, 40, max_len=500)
+    y[qid == 3] = 0.0          # a query without relevant documents
+    y[(qid == 5) & (y == 0)] = -1.0  # negative gains contribute negative NDCG terms
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    rng = np.random.default_rng(59)
+    feats, bases, cands = _ca_groups(rng, X.shape[1], 3, iters=25)
+    feats[0], feats[1] = 0, X.shape[1] - 1
+    cands[0] = o.ca_candidates(bases[0][0], 0.05, 2.0, 25)
+    cands[1] = o.ca_candidates(bases[1][feats[1]], 0.05, 2.0, 25)
+    means, pq = native.evaluate_candidates(g, measure, feats, bases, cands, per_query=True)
+    os.environ["FR_FORCE_GENERIC"] = "1"
+    try:
+        generic = native.evaluate_candidates(g, measure, feats, bases, cands)
+    finally:
+        del os.environ["FR_FORCE_GENERIC"]
+    norms = c.default_norms(measure)
+    for gi in range(3):
+        assert np.array_equal(means[gi], generic[gi]), (measure, gi)
+        for ci in (0, 1, 12, 25, 26, 50):
+            w = bases[gi].copy()
+            w[feats[gi]] = cands[gi][ci]
+            exp, err = c.metric_from_scores(measure, c.score_linear(w), norms)
+            assert err == 0
+            assert np.array_equal(pq[:, gi * 64 + ci], exp), (measure, gi, ci)
+            assert means[gi][ci] == c.evaluate_mean(measure, w, norms)
+    # all-tie candidates (zero weights): ranking decided by the gain/id tie-break alone
+    z = np.zeros((1, X.shape[1]))
+    m0, pq0 = native.evaluate_candidates(g, measure, [2], z, [np.asarray([0.0])], per_query=True)
+    exp, _ = c.metric_from_scores(measure, np.zeros(len(y)), norms)
+    assert np.array_equal(pq0[:, 0], exp)
+
+
+def test_default_measure_training_uses_fullrank_path(trec):
+    X, y, qid = trec["train_X"], trec["train_y"], trec["train_qid"]
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()  # measure "ndcg" (no depth) is the reference's default
+    assert req.measure == "ndcg"
+    req.params.seed, req.params.quiet, req.params.num_restarts, req.params.num_max_iterations = 11, True, 2, 5
+    shard = native.train_model_shard(g, req, 0, 2)
+    assert shard["stats"]["path"] == "fused_fullrank"
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg", req.params.to_dict(), threads=2)
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert shard["stats"]["useful_evals"] == int(exp_e.sum())
