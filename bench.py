@@ -279,6 +279,7 @@ def main():
                 "peak": FP64_VALU_PEAK_TADDS,
                 "unit": "Tadd/s",
                 "frac": (adds_per_launch / avg_s / 1e12 / FP64_VALU_PEAK_TADDS) if avg_s > 0 else 0.0,
+                "measured_ceiling": 35.4,  # pure v_add_f64 stream on this chip, tools/ubench/dpadd.hip
             },
             "kernels_ms": {k: v["total_ms"] for k, v in prof.items()},
             "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "final_allgather_select_ms": collective_ms,
