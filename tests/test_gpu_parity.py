@@ -596,3 +596,73 @@ def test_default_measure_training_uses_fullrank_path(trec):
     for r in shard["restarts"]:
         assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
     assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+
+
+# ---------------------------------------------------------------- tree-ensemble kernel (config 5)
+
+def _rand_tree(rng, X, depth, p_leaf=0.1, nfeat=None):
+    nfeat = X.shape[1] if nfeat is None else nfeat
+    if depth == 0 or rng.random() < p_leaf:
+        return {"LeafNode": float(rng.uniform(-2, 4))}
+    f = int(rng.integers(0, nfeat))
+    col = X[:, min(f, X.shape[1] - 1)]
+    return {"FeatureSplit": {"fid": f, "split": float(np.quantile(col, rng.random())),
+                             "lhs": _rand_tree(rng, X, depth - 1, p_leaf, nfeat),
+                             "rhs": _rand_tree(rng, X, depth - 1, p_leaf, nfeat)}}
+
+
+def _ensemble(trees, weights):
+    return fr.CModel.from_dict({"Ensemble": {"weights": list(weights), "models": [{"DecisionTree": t} for t in trees]}})
+
+
+@pytest.mark.parametrize("shape", ["", "256,1", "256,2", "256,4", "128,2", "128,4", "64,4"])
+def test_tree_kernel_block_shapes(mslr_small, shape, monkeypatch):
+    """Every block shape of the LDS tree walk gives the oracle's scores bit for bit: 77 trees (so the
+    last batches are ragged and padded), missing features (fid >= D reads 0.0), negative weights."""
+    X, y, qid, g, c = mslr_small
+    if shape:
+        monkeypatch.setenv("FR_TREE_SHAPE", shape)
+    rng = np.random.default_rng(21)
+    trees = [_rand_tree(rng, X, 7, nfeat=X.shape[1] + 4) for _ in range(77)]
+    weights = rng.uniform(-1.0, 1.0, len(trees)).tolist()
+    got = native.predict_scores_dense(_ensemble(trees, weights), g)
+    assert np.array_equal(got, c.score_ensemble(trees, weights))
+
+
+def test_tree_kernel_edge_forests(small):
+    X, y, qid, g, c = small
+    rng = np.random.default_rng(22)
+    # 200 stumps and bare leaves: many trees per LDS batch
+    stumps = [_rand_tree(rng, X, 1, p_leaf=0.2) for _ in range(200)]
+    w = rng.uniform(0.0, 1.0, len(stumps)).tolist()
+    assert np.array_equal(native.predict_scores_dense(_ensemble(stumps, w), g), c.score_ensemble(stumps, w))
+    # deep, wide trees (a level wider than the compact encoding's 8-bit child offset): L2 fallback kernel
+    deep = [_rand_tree(rng, X, 11, p_leaf=0.0) for _ in range(3)]
+    assert np.array_equal(native.predict_scores_dense(_ensemble(deep, [1.0, 0.5, 0.25]), g),
+                          c.score_ensemble(deep, [1.0, 0.5, 0.25]))
+    # a single tree inside an ensemble is 0.0 + w * leaf; a bare DecisionTree is the leaf itself (-0.0 survives)
+    t = {"FeatureSplit": {"fid": 0, "split": float(np.median(X[:, 0])), "lhs": {"LeafNode": -0.0}, "rhs": {"LeafNode": 1.5}}}
+    bare = native.predict_scores_dense(fr.CModel.from_dict({"DecisionTree": t}), g)
+    exp = c.score_ensemble([t], [1.0])
+    assert np.array_equal(bare, exp) and np.array_equal(np.signbit(bare), np.signbit(np.where(X[:, 0] <= np.float32(t["FeatureSplit"]["split"]), -0.0, 1.5)))
+    ens1 = native.predict_scores_dense(_ensemble([t], [2.0]), g)
+    assert np.array_equal(ens1, 0.0 + 2.0 * exp) and not np.signbit(ens1).any()
+
+
+def test_tree_kernel_thresholds_at_f32_boundaries():
+    """f64(x) <= split with splits that are not f32 values or lie beyond the f32 range; x = +-inf, NaN, denormals."""
+    vals = np.array([-np.inf, -3.4028235e38, -1.0, -1e-45, -0.0, 0.0, 1e-45, 0.1, 0.5, 1.0, 3.4028235e38, np.inf, np.nan],
+                    dtype=np.float32)
+    X = np.repeat(vals[:, None], 3, axis=1)
+    y = np.zeros(len(vals))
+    qid = np.zeros(len(vals), dtype=np.int64)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    # (infinite / NaN splits cannot be written in the JSON model format, as with serde_json)
+    splits = [0.1, float(np.float32(0.1)), float(np.nextafter(float(np.float32(0.1)), -1.0)), 0.0, -0.0, 1e300, -1e300,
+              3.4028235e38, -3.4028235e38, 1e-46, -1e-46, 0.5]
+    trees = [{"FeatureSplit": {"fid": i % 3, "split": s, "lhs": {"LeafNode": 1.0}, "rhs": {"LeafNode": 2.0}}} for i, s in enumerate(splits)]
+    for t in trees:
+        got = native.predict_scores_dense(fr.CModel.from_dict({"DecisionTree": t}), g)
+        assert np.array_equal(got, c.score_ensemble([t], [1.0])), t
+    w = [1.0] * len(trees)
+    assert np.array_equal(native.predict_scores_dense(_ensemble(trees, w), g), c.score_ensemble(trees, w))
