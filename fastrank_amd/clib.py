@@ -17,6 +17,10 @@ from . import _build
 _MODEL_TYPES = ["SingleFeature", "Linear", "DecisionTree", "Ensemble"]
 
 
+# int (*fr_allreduce_sum_fn)(void *ctx, double *values, size_t n)  (include/fastrank.h)
+ALLREDUCE_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+
+
 class _CResult(C.Structure):
     _fields_ = [("error_message", C.c_void_p), ("success", C.c_void_p)]
 
@@ -69,6 +73,7 @@ def _load():
         "fr_train_model_shard": (vp, [C.c_char_p, vp, C.c_uint32, C.c_uint32]),
         "fr_select_model": (res, [C.c_char_p, C.c_int]),
         "fr_ca_begin": (vp, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "fr_ca_begin_query_shard": (vp, [C.c_char_p, vp, C.c_uint64, ALLREDUCE_SUM_FN, vp, C.POINTER(vp)]),
         "fr_ca_step": (vp, [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
         "fr_ca_state": (vp, [vp]),
         "fr_ca_free": (None, [vp]),

@@ -669,6 +669,35 @@ void* fr_ca_begin(const void* train_request_json, const CDataset* dataset, uint3
     return h;
 }
 
+void* fr_ca_begin_query_shard(const void* train_request_json, const CDataset* dataset, uint64_t total_queries,
+                              fr_allreduce_sum_fn allreduce, void* ctx, const void** error_out) {
+    if (error_out) *error_out = nullptr;
+    FrTrainer* h = nullptr;
+    const void* st = status_call([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
+        if (!rq.is_ca) fr::fail_str("fr_ca_begin_query_shard: only CoordinateAscent");
+        if (!allreduce) fr::fail_str("fr_ca_begin_query_shard: allreduce callback is null!");
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        fr::Evaluator ev = fr::make_evaluator(*ds.view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+        if (total_queries == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+        fr::QueryShard shard;
+        shard.total_queries = total_queries;
+        shard.allreduce = [allreduce, ctx](double* v, size_t n) {
+            if (allreduce(ctx, v, n) != 0) fr::fail_str("query-shard allreduce callback failed");
+        };
+        auto holder = std::make_unique<FrTrainer>();
+        holder->t0 = std::chrono::steady_clock::now();
+        holder->t = std::make_unique<fr::CATrainer>(ds.view, std::move(ev), rq.ca, 0u, rq.ca.num_restarts, std::move(shard));
+        h = holder.release();
+    });
+    if (st) {
+        if (error_out) *error_out = st; else free((void*)st);
+        return nullptr;
+    }
+    return h;
+}
+
 const void* fr_ca_step(void* trainer, uint64_t max_ticks, uint64_t* ticks_done, int* finished) {
     return status_call([&]() {
         if (!trainer) fr::fail_str("trainer pointer is null!");
@@ -807,6 +836,7 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
         fr::DatasetView& view = *ds.view;
         fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
         frdev::DeviceDataset& dev = view.device();
+        dev.set_sums_only(false);
         const size_t d = dev.d();
         std::string err;
         for (size_t g = 0; g < n_groups; g++)

@@ -90,6 +90,9 @@ class DeviceDataset {
     bool download_rank(uint32_t* out_instance_ids /*[n] grouped by query, rank order*/, std::string* err);
     // mean over queries of each of the last result's columns (sequential sum in query order)
     bool reduce_means(size_t ncols, double* out_means, std::string* err);
+    // query-sharded training: every reduction over queries (reduce_means, the line searches) returns the
+    // SUM over this dataset's queries, in the fixed two-level shape, instead of the mean
+    void set_sums_only(bool on);
 
     // --- fused line search (NDCG@k, k <= 20) --------------------------------------------------
     // false for non-NDCG@k measures, k > 20, and datasets with non-finite features

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -706,10 +707,19 @@ inline void evaluate_means_generic(DatasetView& view, const Evaluator& ev, const
 // restarts advance in lock step: one device launch per "feature tick" evaluates every
 // candidate of every live restart's current line search; the host then replays the
 // reference's sequential accept / early-break logic on the returned means.
+// Query-sharded training (SURVEY 8e fallback for fewer restarts than GPUs): this process holds a
+// contiguous block of the queries; `allreduce` must replace values[i] by the sum over all ranks,
+// added in rank order (so every rank gets the same bits), and `total_queries` is the global count.
+struct QueryShard {
+    std::function<void(double* values, size_t n)> allreduce;
+    uint64_t total_queries = 0;
+};
+
 class CATrainer {
   public:
-    CATrainer(std::shared_ptr<DatasetView> view, Evaluator ev, const CAParams& p, uint32_t rbegin, uint32_t rend)
-        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features) {
+    CATrainer(std::shared_ptr<DatasetView> view, Evaluator ev, const CAParams& p, uint32_t rbegin, uint32_t rend,
+              QueryShard shard = QueryShard())
+        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features), shard_(std::move(shard)) {
         if (fids_.empty()) fail_str("assertion failed: data.n_dim() > 0");
         if (view_->instances.empty()) fail_str("assertion failed: !data.instances().is_empty()");
         frdev::DeviceDataset& dev = view_->device();
@@ -742,7 +752,9 @@ class CATrainer {
             std::copy(r.best_w.begin(), r.best_w.end(), w0.begin() + k * d_);
         }
         std::vector<double> means;
+        dev.set_sums_only((bool)shard_.allreduce);
         evaluate_means_generic(*view_, ev_, w0, R, means);
+        global_means(means);
         for (size_t k = 0; k < R; k++) {
             if (means[k] != means[k]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
             rs_[k].best_score = means[k];
@@ -800,6 +812,7 @@ class CATrainer {
             }
         }
         if (!any) return false;
+        dev.set_sums_only((bool)shard_.allreduce);  // the dataset object may be shared with other callers
         if (fused_) {
             std::string _err;
             if (!dev.linesearch_ndcg(ev_.depth, ev_.norms.data(), groups_, &means_, &_err)) fail_str(_err);
@@ -812,6 +825,7 @@ class CATrainer {
         } else {
             evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
         }
+        global_means(means_);
         stats_.ticks++;
         stats_.groups += (fused_ || fullrank_) ? groups_.size() : gen_B;
         for (Restart& r : rs_) {
@@ -865,6 +879,13 @@ class CATrainer {
     const CAParams& params() const { return p_; }
 
   private:
+    // query-sharded mode: `v` holds this shard's sums; make them global means
+    void global_means(std::vector<double>& v) {
+        if (!shard_.allreduce) return;
+        shard_.allreduce(v.data(), v.size());
+        const double q = (double)shard_.total_queries;
+        for (double& x : v) x = shard_.total_queries ? x / q : 0.0;
+    }
     struct Restart {
         uint32_t id;
         Rand64 rand;
@@ -886,6 +907,7 @@ class CATrainer {
     Evaluator ev_;
     CAParams p_;
     std::vector<uint32_t> fids_;
+    QueryShard shard_;
     size_t d_ = 0;
     uint32_t model_dim_ = 0;
     bool fused_ = false;

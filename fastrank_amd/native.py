@@ -1,13 +1,13 @@
 """Extensions of the C ABI that have no reference counterpart (include/fastrank.h part 2):
-dense result buffers, the batched line-search evaluator, restart-sharded multi-GPU training and
-HIP-event kernel timing.  numpy is used only to hold buffers that cross the ABI."""
+dense result buffers, the batched line-search evaluator, restart-sharded and query-sharded multi-GPU
+training and HIP-event kernel timing.  numpy is used only to hold buffers that cross the ABI."""
 import ctypes as C
 import json
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .clib import CDataset, CModel, CQRel, _json_reply, _load, _status, _take_str, _unwrap
+from .clib import ALLREDUCE_SUM_FN, CDataset, CModel, CQRel, _json_reply, _load, _status, _take_str, _unwrap
 
 
 def device_count() -> int:
@@ -156,6 +156,74 @@ class CoordinateAscentRun:
             self.close()
         except Exception:
             pass
+
+
+def rank_ordered_sum(values: "np.ndarray", group=None) -> "np.ndarray":
+    """Sum of a float64 vector over all ranks, added in rank order, so every rank gets the same
+    bits (a ring all-reduce does not promise that).  One all_gather of len(values) doubles over
+    RCCL/xGMI (backend "nccl") or gloo."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return np.array(values, dtype=np.float64)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, mine, group=group)
+    total = parts[0].cpu().numpy().copy()
+    for t in parts[1:]:
+        total = total + t.cpu().numpy()
+    return total
+
+
+class QueryShardedRun(CoordinateAscentRun):
+    """Coordinate ascent with the QUERIES sharded over the ranks (the fallback for runs
+    with fewer restarts than GPUs): `dataset` is this rank's block of queries, every rank runs all
+    restarts in lock step, and after each device evaluation the per-candidate sums are combined with
+    rank_ordered_sum (<= 13 KB per tick).  Every rank ends with identical restarts."""
+
+    def __init__(self, dataset: CDataset, train_req, total_queries: Optional[int] = None, group=None):
+        local_q = num_queries(dataset)
+        if total_queries is None:
+            total_queries = int(rank_ordered_sum(np.array([float(local_q)]), group)[0])
+
+        def reduce_cb(_ctx, values, n):
+            try:
+                arr = np.ctypeslib.as_array(values, shape=(n,))
+                arr[:] = rank_ordered_sum(arr, group)
+                return 0
+            except Exception as exc:  # surfaces as an error envelope from fr_ca_step
+                self._callback_error = exc
+                return 1
+
+        self._callback_error = None
+        self._callback = ALLREDUCE_SUM_FN(reduce_cb)  # keep alive as long as the trainer
+        err = C.c_void_p()
+        request = json.dumps(train_req.to_dict()).encode("utf-8")
+        self.pointer = _load().fr_ca_begin_query_shard(request, dataset.pointer, int(total_queries), self._callback, None, C.byref(err))
+        if not self.pointer:
+            _status(err.value)
+            raise RuntimeError("fr_ca_begin_query_shard failed")
+        self._dataset = dataset
+        self.finished = False
+        self.total_queries = int(total_queries)
+
+
+def train_model_query_sharded(dataset: CDataset, train_req, total_queries: Optional[int] = None, group=None) -> CModel:
+    """Trains on query shards: call on every rank with that rank's block of queries (e.g.
+    `full.subsample_queries(my_qids)` or a per-rank file).  Returns the same model on every rank."""
+    run = QueryShardedRun(dataset, train_req, total_queries, group)
+    try:
+        while not run.finished:
+            run.step(1 << 20)
+        restarts = run.state()["restarts"]
+    finally:
+        run.close()
+    model = select_model(restarts, bool(train_req.params.output_ensemble))
+    model.params = train_req
+    return model
 
 
 def select_model(restarts: List[Dict], output_ensemble: bool = False) -> CModel:

@@ -120,6 +120,15 @@ const void *fr_train_model_shard(const void *train_request_json, const CDataset 
  * fr_ca_begin returns NULL and sets *error_out (free_str) on failure. */
 void *fr_ca_begin(const void *train_request_json, const CDataset *dataset, uint32_t restart_begin,
                   uint32_t restart_end, const void **error_out);
+/* Query-sharded form (fewer restarts than GPUs).  `dataset` holds this rank's block of
+ * the queries; all ranks run ALL restarts in lock step.  After every device evaluation the trainer
+ * hands the per-candidate SUMS over its queries to `allreduce(ctx, values, n)`, which must replace
+ * values[i] with the sum over all ranks added in rank order (identical bits on every rank; e.g.
+ * all_gather + a sequential add) and return 0; the trainer divides by total_queries.  Step and read
+ * it with fr_ca_step / fr_ca_state; every rank ends with the same restarts. */
+typedef int (*fr_allreduce_sum_fn)(void *ctx, double *values, size_t n);
+void *fr_ca_begin_query_shard(const void *train_request_json, const CDataset *dataset, uint64_t total_queries,
+                              fr_allreduce_sum_fn allreduce, void *ctx, const void **error_out);
 /* Runs up to max_ticks ticks; NULL on success. *finished = 1 once every restart converged. */
 const void *fr_ca_step(void *trainer, uint64_t max_ticks, uint64_t *ticks_done, int *finished);
 /* JSON {"restarts":[...],"stats":{...},"finished":bool} (free_str). */

@@ -457,8 +457,19 @@ static size_t g_mean_segment = 0;
 void oracle_set_mean_segment(size_t s) { g_mean_segment = s; }
 size_t oracle_get_mean_segment(void) { return g_mean_segment; }
 
-static double mean_seq(const double *v, size_t n) {
-    if (n == 0) return 0.0;
+/* Query-sharded training (include/fastrank.h fr_ca_begin_query_shard) fixes one more level of the
+ * shape: each shard [start_r, start_{r+1}) is summed as above, the shard sums are added in rank
+ * order, and the total is divided by the number of queries.  oracle_set_mean_shards(NULL, 0) turns
+ * it off. */
+#define ORACLE_MAX_SHARDS 64
+static size_t g_shard_starts[ORACLE_MAX_SHARDS + 1];
+static size_t g_nshards = 0;
+void oracle_set_mean_shards(const size_t *starts /*[nshards]*/, size_t nshards) {
+    g_nshards = nshards <= ORACLE_MAX_SHARDS ? nshards : 0;
+    for (size_t i = 0; i < g_nshards; i++) g_shard_starts[i] = starts[i];
+}
+
+static double sum_shape(const double *v, size_t n) {
     double sum = 0.0;
     if (g_mean_segment == 0) {
         for (size_t i = 0; i < n; i++) sum += v[i];
@@ -470,7 +481,20 @@ static double mean_seq(const double *v, size_t n) {
             sum += part;
         }
     }
-    return sum / (double)n;
+    return sum;
+}
+
+static double mean_seq(const double *v, size_t n) {
+    if (n == 0) return 0.0;
+    if (g_nshards == 0) return sum_shape(v, n) / (double)n;
+    double total = 0.0;
+    for (size_t r = 0; r < g_nshards; r++) {
+        size_t a = g_shard_starts[r] < n ? g_shard_starts[r] : n;
+        size_t b = (r + 1 < g_nshards && g_shard_starts[r + 1] < n) ? g_shard_starts[r + 1] : n;
+        double part = b > a ? sum_shape(v + a, b - a) : 0.0;
+        total = r == 0 ? part : total + part;
+    }
+    return total / (double)n;
 }
 
 /* exposed so tests can reduce a per-query vector with the selected shape */

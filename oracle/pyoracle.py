@@ -75,6 +75,8 @@ def lib():
     L.oracle_ca_candidates.restype = sz
     L.oracle_ca_candidates.argtypes = [dbl, dbl, dbl, u32, vp]
     L.oracle_set_mean_segment.argtypes = [sz]
+    L.oracle_set_mean_shards.argtypes = [C.c_void_p, sz]
+    L.oracle_set_mean_shards.restype = None
     L.oracle_get_mean_segment.restype = sz
     L.oracle_mean.restype = dbl
     L.oracle_mean.argtypes = [vp, sz]
@@ -254,6 +256,13 @@ class Dataset:
 
 
 DEVICE_MEAN_SEGMENT = 256  # fastrank_amd/csrc/device.hip MEAN_SEG
+
+
+def set_mean_shards(starts=None) -> None:
+    """Query-sharded mean shape: starts[r] = index (in dataset query order) of shard r's first query.
+    None / [] turns it off."""
+    arr = np.ascontiguousarray(starts if starts is not None else [], dtype=np.uint64)
+    lib().oracle_set_mean_shards(arr.ctypes.data_as(C.c_void_p) if arr.size else None, int(arr.size))
 
 
 def set_mean_segment(seg: int) -> None:

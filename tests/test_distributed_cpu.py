@@ -68,3 +68,53 @@ def test_two_rank_gather_and_select_matches_single_process(tmp_path, output_ense
 def test_gather_without_process_group_is_identity():
     mine = [{"restart_id": 1, "score": 0.2, "weights": [1.0]}, {"restart_id": 0, "score": 0.1, "weights": [2.0]}]
     assert [r["restart_id"] for r in native.gather_restarts(mine, 2)] == [0, 1]
+
+
+def _sum_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the query-sharded trainer's exchange: per-candidate sums of this rank's queries
+    rng = np.random.default_rng(100 + rank)
+    mine = rng.uniform(0, 1, 1632) * (1e-9 if rank == 0 else 1e9)  # badly conditioned on purpose
+    total = native.rank_ordered_sum(mine)
+    np.save(os.path.join(out_dir, "sum%d.npy" % rank), total)
+    np.save(os.path.join(out_dir, "mine%d.npy" % rank), mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_ordered_sum_is_bitwise_identical_on_every_rank(tmp_path):
+    world = 3
+    mp.spawn(_sum_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sums = [np.load(tmp_path / ("sum%d.npy" % r)) for r in range(world)]
+    mine = [np.load(tmp_path / ("mine%d.npy" % r)) for r in range(world)]
+    assert all(np.array_equal(sums[0], s) for s in sums[1:])
+    assert np.array_equal(sums[0], (mine[0] + mine[1]) + mine[2]), "added in rank order"
+    assert np.array_equal(native.rank_ordered_sum(mine[0]), mine[0])  # no process group: identity
+
+
+def test_oracle_sharded_mean_shape():
+    """mean = (sum over shards, in rank order, of the shard's segment-shaped sum) / nq -- the shape
+    fr_ca_begin_query_shard fixes (include/fastrank.h)."""
+    v = np.random.default_rng(3).uniform(0, 1, 1000)
+    try:
+        o.set_mean_segment(256)
+        o.set_mean_shards([0, 300, 900])
+
+        def seg(x):
+            t = 0.0
+            for s0 in range(0, len(x), 256):
+                part = 0.0
+                for e in x[s0:s0 + 256]:
+                    part += e
+                t += part
+            return t
+
+        exp = ((seg(v[:300]) + seg(v[300:900])) + seg(v[900:])) / 1000.0
+        assert o.mean(v) == exp
+        o.set_mean_shards(None)
+        assert o.mean(v) == seg(v) / 1000.0
+    finally:
+        o.set_mean_shards(None)
+        o.set_mean_segment(0)
