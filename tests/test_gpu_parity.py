@@ -666,3 +666,36 @@ def test_tree_kernel_thresholds_at_f32_boundaries():
         assert np.array_equal(got, c.score_ensemble([t], [1.0])), t
     w = [1.0] * len(trees)
     assert np.array_equal(native.predict_scores_dense(_ensemble(trees, w), g), c.score_ensemble(trees, w))
+
+
+def test_query_longer_than_the_lds_sort():
+    """One query of 20 000 documents (beyond the 8192-document LDS sort and the 2048-document
+    rank-counting kernel): the general evaluator sorts it in global memory; the fused NDCG@k line
+    search takes it as it is.  The reference has no length limit (src/evaluators.rs:186-224)."""
+    rng = np.random.default_rng(61)
+    lens = np.array([20000, 3, 700, 1, 9000])
+    qid = np.repeat(np.arange(1, 1 + len(lens), dtype=np.int64), lens)
+    n = len(qid)
+    X = np.round(rng.normal(0, 3, (n, 6))).astype(np.float32)  # heavy score ties
+    X[:, 5] = rng.normal(0, 1, n).astype(np.float32)
+    y = rng.choice([0.0, 0.0, 0.0, 1.0, 2.0, 4.0], size=n)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    w = np.array([0.4, -0.2, 0.1, 0.0, 0.3, 0.05])
+    model = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+    ids, offs = native.rank_order(model, g)
+    _, exp_rank, err = c.metric_from_scores("ndcg", c.score_linear(w), want_rank=True)
+    assert err == 0 and np.array_equal(ids, exp_rank)
+    for measure in ("ndcg", "ndcg@10", "ndcg@5000", "map", "mrr"):
+        exp, _ = c.metric_from_scores(measure, c.score_linear(w))
+        got = g.evaluate(model, measure)
+        assert got == dict(zip((str(int(q)) for q in c.query_ids()), exp.tolist())), measure
+    req = fr.TrainRequest.coordinate_ascent()
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 3, True, 1, 2
+    for measure, path in (("ndcg@10", "fused_linesearch"), ("map", "generic_sort")):
+        req.measure = measure
+        shard = native.train_model_shard(g, req, 0, 1)
+        assert shard["stats"]["path"] == path
+        exp_s, exp_w, _, err = c.ca_learn(measure, p.to_dict(), threads=1, max_evals_per_restart=0)
+        assert err == 0
+        assert shard["restarts"][0]["score"] == exp_s[0] and shard["restarts"][0]["weights"] == exp_w[0].tolist()
