@@ -11,7 +11,9 @@
 //                           and tree_ensemble_kernel (L2 fallback)
 //   kernels_metric.inc      metric_sort_kernel (LDS bitonic sort + NDCG/AP/RR in the reference's
 //                           summation order) and the fixed-shape mean reduction
-//   kernels_linesearch.inc  linesearch_ndcg_kernel: the fused NDCG@k line search (the hot path)
+//   kernels_linesearch.inc  linesearch_ndcg_kernel: the exact fused NDCG@k line search
+//   kernels_verify.inc      linesearch_verify_kernel: bound-and-verify NDCG@k line search (the hot path; the exact
+//                           kernel recomputes the pairs it cannot verify)
 //   kernels_fullrank.inc    linesearch_scores_kernel + rank_metric_kernel: AP / RR / depth-less NDCG
 //   device_dataset.inc      DeviceDataset: HBM layout (runs, tiles, tables) and every launcher
 #include "device.hpp"
@@ -35,6 +37,7 @@ namespace frdev {
 #include "kernels_tree.inc"
 #include "kernels_metric.inc"
 #include "kernels_linesearch.inc"
+#include "kernels_verify.inc"
 #include "kernels_fullrank.inc"
 #include "device_dataset.inc"
 

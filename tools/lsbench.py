@@ -62,7 +62,7 @@ def main():
     native.profile_enable(False)
     st = native.profile_stats()
     evals = sum(len(c) for c in cands)
-    k = st.get("linesearch_ndcg_kernel") or st.get("rank_metric_kernel") or st.get("metric_sort_kernel")
+    k = st.get("linesearch_verify_kernel") or st.get("linesearch_ndcg_kernel") or st.get("rank_metric_kernel") or st.get("metric_sort_kernel")
     print("shape=%s groups=%d evals/launch=%d  kernel avg %.3f ms  wall/call %.3f ms  -> %.0f evals/s (kernel)  mean[0][:3]=%s" % (
         args.shape, args.groups, evals, k["avg_ms"], wall * 1e3, evals / (k["avg_ms"] * 1e-3), means[0][:3]))
     for name, v in sorted(st.items()):
