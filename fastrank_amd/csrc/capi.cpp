@@ -141,6 +141,8 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("seconds", Value::number(s.seconds));
     o.set("path", Value::string(s.path));
     o.set("restarts", Value::uint(s.restarts));
+    o.set("verify_pairs", Value::uint(s.verify_pairs));
+    o.set("verify_redone", Value::uint(s.verify_redone));
     return o;
 }
 

@@ -100,6 +100,8 @@ class DeviceDataset {
     // evaluates every candidate of every group; means[g*64 + c]
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);
+    // running totals: (run, group) pairs given to the bound-and-verify kernel / recomputed exactly
+    void verify_counters(unsigned long long* pairs, unsigned long long* redone) const;
     // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----
     bool fullrank_supported(int measure, int64_t depth) const;
     bool linesearch_fullrank(int measure, int64_t depth, const double* norms, const std::vector<LineGroup>& groups,

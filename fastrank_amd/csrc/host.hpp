@@ -648,8 +648,11 @@ struct TrainStats {
     uint64_t ticks = 0;         // batched launches
     uint64_t groups = 0;
     double seconds = 0.0;
-    std::string path;           // "fused_linesearch" | "generic_sort"
+    std::string path;           // "fused_linesearch" | "fused_fullrank" | "generic_sort"
     uint32_t restarts = 0;
+    // fused_linesearch: (run, group) pairs evaluated by the bound-and-verify kernel, and how many of
+    // them it could not verify (recomputed by the exact kernel)
+    uint64_t verify_pairs = 0, verify_redone = 0;
 };
 
 // coordinate_ascent.rs:72-82
@@ -815,7 +818,12 @@ class CATrainer {
         dev.set_sums_only((bool)shard_.allreduce);  // the dataset object may be shared with other callers
         if (fused_) {
             std::string _err;
+            unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+            dev.verify_counters(&p0, &r0);
             if (!dev.linesearch_ndcg(ev_.depth, ev_.norms.data(), groups_, &means_, &_err)) fail_str(_err);
+            dev.verify_counters(&p1, &r1);
+            stats_.verify_pairs += p1 - p0;
+            stats_.verify_redone += r1 - r0;
             check_flags(dev);
         } else if (fullrank_) {
             std::string _err;

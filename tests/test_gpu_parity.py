@@ -701,3 +701,74 @@ def test_query_longer_than_the_lds_sort():
         exp_s, exp_w, _, err = c.ca_learn(measure, p.to_dict(), threads=1, max_evals_per_restart=0)
         assert err == 0
         assert shard["restarts"][0]["score"] == exp_s[0] and shard["restarts"][0]["weights"] == exp_w[0].tolist()
+
+
+# ---------------------------------------------------------------- bound-and-verify line search
+
+def _train_stats(g, req):
+    shard = native.train_model_shard(g, req, 0, int(req.params.num_restarts))
+    return shard, shard["stats"]
+
+
+def test_verify_kernel_falls_back_on_ties_and_duplicates():
+    """The hot path evaluates from approximate scores and keeps a value only if the order of the
+    best documents is provable; queries with exactly tied or nearly tied scores must come from the
+    exact kernel.  Duplicated documents (exact ties whose order is decided by gain / id), integer
+    features and a single-feature model force that path; the trajectory must still be the oracle's."""
+    rng = np.random.default_rng(71)
+    X, y, qid = synth_dataset(73, 6000, 8, 60, max_len=300)
+    X = np.round(X * 2).astype(np.float32)          # few distinct values per column
+    dup = rng.integers(0, len(y), 1500)              # duplicate rows inside the same query
+    for i in dup:
+        j = i + 1 if i + 1 < len(y) and qid[i + 1] == qid[i] else i
+        X[j] = X[i]
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 9, True, 2, 4
+    shard, st = _train_stats(g, req)
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["path"] == "fused_linesearch"
+    assert st["verify_redone"] > 0, "this dataset must exercise the exact fallback"
+    # per-query values of single candidates, including the all-ties candidate (zero weights)
+    feats = [0, 3]
+    bases = np.zeros((2, X.shape[1]))
+    bases[1, 5] = 1.0
+    cands = [np.asarray([0.0, 1.0, -1.0]), np.asarray([0.0, 0.5])]
+    means, pq = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands, per_query=True)
+    for gi in range(2):
+        for ci in range(len(cands[gi])):
+            w = bases[gi].copy()
+            w[feats[gi]] = cands[gi][ci]
+            exp, _ = c.metric_from_scores("ndcg@10", c.score_linear(w))
+            assert np.array_equal(pq[:, gi * 64 + ci], exp), (gi, ci)
+
+
+def test_verify_kernel_near_ties_below_the_error_bound():
+    """Scores that differ by less than the proven error bound (here ~1e-13 relative) cannot be ordered
+    from the approximate sums: the pair is recomputed exactly and the result is the oracle's."""
+    n, d = 400, 6
+    rng = np.random.default_rng(77)
+    X = rng.uniform(1.0, 2.0, (n, d)).astype(np.float32)
+    X[1::2] = X[0::2]                                   # pairs of identical documents ...
+    X[1::2, 0] = np.nextafter(X[0::2, 0], np.float32(4))  # ... one float32 ulp apart in feature 0
+    y = rng.choice([0.0, 1.0, 2.0, 3.0], size=n)
+    qid = np.repeat(np.arange(1, 5, dtype=np.int64), n // 4)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    bases = np.full((1, d), 1.0 / d)
+    bases[0, 0] = 1e-9                                   # the ulp in feature 0 moves a score by ~1e-16
+    cands = [np.asarray([1e-9, 0.0, 1e-3, -1e-3])]
+    native.profile_reset()
+    native.profile_enable(True)
+    means, pq = native.evaluate_candidates(g, "ndcg@5", [0], bases, cands, per_query=True)
+    native.profile_enable(False)
+    assert native.profile_stats()["linesearch_ndcg_kernel"]["launches"] == 1, "exact fallback expected"
+    for ci in range(4):
+        w = bases[0].copy()
+        w[0] = cands[0][ci]
+        exp, _ = c.metric_from_scores("ndcg@5", c.score_linear(w))
+        assert np.array_equal(pq[:, ci], exp), ci
