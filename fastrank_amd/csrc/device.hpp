@@ -49,6 +49,18 @@ struct LineGroup {
     uint32_t feature = 0;
     std::vector<double> weights;     // [d] base weights (entry `feature` ignored)
     std::vector<double> candidates;  // <= 64 values for w[feature], in evaluation order
+    // Optional (bound-and-verify path only): a resident per-document sum R ~ sum_j x_j * v_j for some
+    // vector v (the trainer's un-normalised best weights) lives in slot `resident_slot`; the base dot
+    // product is then formed as  A = R / resident_norm - x_f * resident_base_f  instead of from the
+    // feature tiles (weights == v / resident_norm up to rounding).  `resident_err` bounds |R - sum_j x_j v_j|
+    // for every document.  A pending update (the previous tick accepted a candidate, so v changed in one
+    // coordinate after being normalised) is applied first:
+    //   R <- fma(x_uf, upd_cand, fma(-x_uf, upd_base_f, R / upd_norm))
+    int resident_slot = -1;
+    double resident_norm = 1.0, resident_base_f = 0.0, resident_err = 0.0;
+    bool has_update = false;
+    uint32_t upd_feature = 0;
+    double upd_norm = 1.0, upd_base_f = 0.0, upd_cand = 0.0;
 };
 
 struct KernelStat {
@@ -100,6 +112,11 @@ class DeviceDataset {
     // evaluates every candidate of every group; means[g*64 + c]
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);
+    // resident per-document sums for LineGroup::resident_slot: `slots` double-buffered arrays of np doubles
+    bool resident_reserve(size_t slots, std::string* err);
+    // slot <- the scores of score slot b of the last score_linear() call (exact ordered sums)
+    bool resident_store_from_scores(size_t slot, size_t b, std::string* err);
+    const std::vector<double>& column_absmax() const;  // per-column max |x|
     // running totals: (run, group) pairs given to the bound-and-verify kernel / recomputed exactly
     void verify_counters(unsigned long long* pairs, unsigned long long* redone) const;
     // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----

@@ -764,6 +764,22 @@ class CATrainer {
             stats_.useful_evals++;
             stats_.raw_evals++;
         }
+        // Resident base sums for the bound-and-verify kernel (device.hpp LineGroup): one slot per restart holds
+        // R ~ sum_j x_j * best_w_j for every document, so a tick reads 24 bytes per document and restart instead
+        // of the whole feature row.  FR_LS_RESIDENT=0 turns it off (every tick then forms the sums from the tiles).
+        const char* res_env = getenv("FR_LS_RESIDENT");
+        if (fused_ && !(res_env && res_env[0] == '0')) {
+            std::string _err;
+            if (dev.resident_reserve(R, &_err)) {
+                resident_ = true;
+                std::vector<size_t> all(R);
+                for (size_t k = 0; k < R; k++) {
+                    rs_[k].slot = (int)k;
+                    all[k] = k;
+                }
+                refresh_resident(all);
+            }
+        }
     }
 
     bool done() const {
@@ -779,6 +795,12 @@ class CATrainer {
         gen_w_.clear();
         size_t gen_B = 0;
         bool any = false;
+        if (resident_) {
+            std::vector<size_t> stale;
+            for (size_t k = 0; k < rs_.size(); k++)
+                if (!rs_[k].done && rs_[k].res_updates >= 256) stale.push_back(k);
+            if (!stale.empty()) refresh_resident(stale);
+        }
         for (Restart& r : rs_) {
             if (r.done) continue;
             any = true;
@@ -792,7 +814,15 @@ class CATrainer {
             uint32_t f = r.order[r.pos];
             r.start_score = r.best_score;
             r.base = r.best_w;
-            if (p_.normalize) l1_normalize(r.base);  // entries >= model_dim are 0 and stay 0
+            r.norm = 1.0;
+            if (p_.normalize) {  // l1_normalize (entries >= model_dim are 0 and stay 0), keeping the divisor
+                double sum = 0.0;
+                for (double x : r.base) sum += std::fabs(x);
+                if (sum > 0.0) {
+                    for (double& x : r.base) x /= sum;
+                    r.norm = sum;
+                }
+            }
             double orig = r.base[f];
             line_candidates(orig, p_, r.cands, r.block_len);
             if (fused_ || fullrank_) {
@@ -802,6 +832,17 @@ class CATrainer {
                     lg.feature = f;
                     lg.weights = r.base;
                     lg.candidates.assign(r.cands.begin() + c0, r.cands.begin() + std::min(r.cands.size(), c0 + 64));
+                    if (resident_) {
+                        lg.resident_slot = r.slot;
+                        lg.resident_norm = r.norm;
+                        lg.resident_base_f = orig;
+                        lg.resident_err = r.res_err;
+                        lg.has_update = r.pend;
+                        lg.upd_feature = r.pend_f;
+                        lg.upd_norm = r.pend_norm;
+                        lg.upd_base_f = r.pend_base_f;
+                        lg.upd_cand = r.pend_cand;
+                    }
                     groups_.push_back(std::move(lg));
                 }
             } else {
@@ -825,6 +866,9 @@ class CATrainer {
             stats_.verify_pairs += p1 - p0;
             stats_.verify_redone += r1 - r0;
             check_flags(dev);
+            if (resident_)
+                for (Restart& r : rs_)
+                    if (!r.done) r.pend = false;  // the device applied the pending updates of this tick's groups
         } else if (fullrank_) {
             std::string _err;
             if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_, &means_, &_err))
@@ -841,6 +885,7 @@ class CATrainer {
             uint32_t f = r.order[r.pos];
             // replay coordinate_ascent.rs:145-176 over the batched results
             size_t c = 0;
+            long accepted = -1;  // index of the last accepted candidate of this line search
             for (int s = 0; s < 3; s++) {
                 for (uint32_t it = 0; it < r.block_len[s]; it++, c++) {
                     double sc = (fused_ || fullrank_) ? means_[(r.first_group + c / 64) * 64 + (c % 64)]
@@ -850,6 +895,7 @@ class CATrainer {
                         r.best_score = sc;
                         r.best_w = r.base;
                         r.best_w[f] = r.cands[c];
+                        accepted = (long)c;
                         if (!p_.quiet)
                             printf("%4u|%-16s|%9.3f|%9.3f\n", r.id, view_->core->feature_name(f).c_str(), r.cands[c], sc);
                     }
@@ -857,6 +903,22 @@ class CATrainer {
                 if (r.best_score - r.start_score > p_.tolerance) break;  // :174
             }
             stats_.raw_evals += r.cands.size();
+            if (resident_ && accepted >= 0) {
+                // best_w became base with [f] = cand: the resident sum follows on the device at the next visit,
+                //   R' = fma(x_f, cand, fma(-x_f, base_f, R * (1/norm)))  ~  sum_j x_j * best_w'_j,
+                // and its error bound follows here: the old one shrinks by 1/norm, the reciprocal, the two products
+                // and the two roundings add at most 8 u * T (T = sum_j |x_j best_w'_j| + |x_f base_f|, via column maxima)
+                const std::vector<double>& X = dev.column_absmax();
+                double T = std::fabs(r.base[f]) * X[f];
+                for (size_t j = 0; j < d_; j++) T += std::fabs(r.best_w[j]) * X[j];
+                r.res_err = 1.002 * r.res_err / r.norm + 8.0 * std::ldexp(1.0, -53) * T * (1.0 + 1e-6);
+                r.res_updates++;
+                r.pend = true;
+                r.pend_f = f;
+                r.pend_norm = r.norm;
+                r.pend_base_f = r.base[f];
+                r.pend_cand = r.cands[(size_t)accepted];
+            }
             if (r.best_score - r.start_score > p_.tolerance) r.successes++;  // :179-182
             r.pos++;
             if (r.pos == r.order.size()) {
@@ -887,6 +949,30 @@ class CATrainer {
     const CAParams& params() const { return p_; }
 
   private:
+    // Exact resident sums for the given restarts: score_linear (ordered f64 sums of best_w) -> slot.
+    void refresh_resident(const std::vector<size_t>& which) {
+        frdev::DeviceDataset& dev = view_->device();
+        const std::vector<double>& X = dev.column_absmax();
+        const size_t ld = (dev.n() + 63) / 64 * 64;
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(512, (size_t(2) << 30) / (ld * sizeof(double))));
+        std::vector<double> w;
+        for (size_t b0 = 0; b0 < which.size(); b0 += chunk) {
+            const size_t bn = std::min(chunk, which.size() - b0);
+            w.assign(bn * d_, 0.0);
+            for (size_t k = 0; k < bn; k++) std::copy(rs_[which[b0 + k]].best_w.begin(), rs_[which[b0 + k]].best_w.end(), w.begin() + k * d_);
+            std::string _err;
+            if (!dev.score_linear(bn, w.data(), &_err)) fail_str(_err);
+            for (size_t k = 0; k < bn; k++) {
+                Restart& r = rs_[which[b0 + k]];
+                if (!dev.resident_store_from_scores((size_t)r.slot, k, &_err)) fail_str(_err);
+                double T = 0.0;
+                for (size_t j = 0; j < d_; j++) T += std::fabs(r.best_w[j]) * X[j];
+                r.res_err = 1.1 * (double)(d_ + 1) * std::ldexp(1.0, -53) * T;  // gamma_D * T of an ordered sum
+                r.res_updates = 0;
+                r.pend = false;
+            }
+        }
+    }
     // query-sharded mode: `v` holds this shard's sums; make them global means
     void global_means(std::vector<double>& v) {
         if (!shard_.allreduce) return;
@@ -909,6 +995,14 @@ class CATrainer {
         uint32_t block_len[3] = {0, 0, 0};
         size_t first_group = 0;
         double start_score = 0.0;
+        // resident base sum of this restart on the device (see the constructor)
+        int slot = -1;
+        double norm = 1.0;         // l1 norm the current base was divided by
+        double res_err = 0.0;      // bound on |R - sum_j x_j best_w_j| over all documents (incl. a pending update)
+        uint32_t res_updates = 0;  // incremental updates since the last exact refresh
+        bool pend = false;         // best_w changed last tick: the device still has to update R
+        uint32_t pend_f = 0;
+        double pend_norm = 1.0, pend_base_f = 0.0, pend_cand = 0.0;
         Restart(uint32_t i, uint64_t seed) : id(i), rand(seed) {}
     };
     std::shared_ptr<DatasetView> view_;
@@ -920,6 +1014,7 @@ class CATrainer {
     uint32_t model_dim_ = 0;
     bool fused_ = false;
     bool fullrank_ = false;
+    bool resident_ = false;
     std::vector<Restart> rs_;
     std::vector<frdev::LineGroup> groups_;
     std::vector<double> gen_w_, means_;
