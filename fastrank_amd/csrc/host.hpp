@@ -772,6 +772,7 @@ class CATrainer {
             std::string _err;
             if (dev.resident_reserve(R, &_err)) {
                 resident_ = true;
+                if (const char* e = getenv("FR_RESIDENT_REFRESH")) res_refresh_ = (uint32_t)std::max(1, atoi(e));
                 std::vector<size_t> all(R);
                 for (size_t k = 0; k < R; k++) {
                     rs_[k].slot = (int)k;
@@ -798,7 +799,7 @@ class CATrainer {
         if (resident_) {
             std::vector<size_t> stale;
             for (size_t k = 0; k < rs_.size(); k++)
-                if (!rs_[k].done && rs_[k].res_updates >= 256) stale.push_back(k);
+                if (!rs_[k].done && rs_[k].res_updates >= res_refresh_) stale.push_back(k);
             if (!stale.empty()) refresh_resident(stale);
         }
         for (Restart& r : rs_) {
@@ -1015,6 +1016,7 @@ class CATrainer {
     bool fused_ = false;
     bool fullrank_ = false;
     bool resident_ = false;
+    uint32_t res_refresh_ = 256;  // incremental updates of a resident sum between exact refreshes
     std::vector<Restart> rs_;
     std::vector<frdev::LineGroup> groups_;
     std::vector<double> gen_w_, means_;

@@ -772,3 +772,25 @@ def test_verify_kernel_near_ties_below_the_error_bound():
         w[0] = cands[0][ci]
         exp, _ = c.metric_from_scores("ndcg@5", c.score_linear(w))
         assert np.array_equal(pq[:, ci], exp), ci
+
+
+@pytest.mark.parametrize("env", [{}, {"FR_RESIDENT_REFRESH": "2"}, {"FR_LS_RESIDENT": "0"}, {"FR_VERIFY_GW": "4"},
+                                 {"FR_LS_EXACT": "1"}])
+def test_trainer_variants_share_one_trajectory(small, env, monkeypatch):
+    """Resident base sums (updated incrementally on acceptance, refreshed exactly every N updates), sums
+    from the tiles, several groups per wave, exact kernel only: all of them train to the oracle's result."""
+    X, y, qid, g, c = small
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 13, True, 3, 6
+    shard = native.train_model_shard(g, req, 0, 3)   # to convergence
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=3)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]], env
+        assert r["weights"] == exp_w[r["restart_id"]].tolist(), env
+    assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+    assert shard["stats"]["ticks"] > 48, "several passes over the 24 features"
