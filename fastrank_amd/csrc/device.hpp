@@ -57,6 +57,7 @@ struct LineGroup {
     // coordinate after being normalised) is applied first:
     //   R <- fma(x_uf, upd_cand, fma(-x_uf, upd_base_f, R / upd_norm))
     int resident_slot = -1;
+    uint64_t resident_owner = 0;  // ticket from resident_reserve(); a stale ticket means "form A from the tiles"
     double resident_norm = 1.0, resident_base_f = 0.0, resident_err = 0.0;
     bool has_update = false;
     uint32_t upd_feature = 0;
@@ -113,9 +114,12 @@ class DeviceDataset {
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);
     // resident per-document sums for LineGroup::resident_slot: `slots` double-buffered arrays of np doubles
-    bool resident_reserve(size_t slots, std::string* err);
-    // slot <- the scores of score slot b of the last score_linear() call (exact ordered sums)
-    bool resident_store_from_scores(size_t slot, size_t b, std::string* err);
+    // Returns an owner ticket (0 on failure).  A later reserve by someone else takes the buffers over: groups
+    // and stores that carry the old ticket are then treated as non-resident / refused.
+    uint64_t resident_reserve(size_t slots, std::string* err);
+    // slot <- the scores of score slot b of the last score_linear() call (exact ordered sums); false with an
+    // empty *err when the ticket is stale
+    bool resident_store_from_scores(uint64_t owner, size_t slot, size_t b, std::string* err);
     const std::vector<double>& column_absmax() const;  // per-column max |x|
     // running totals: (run, group) pairs given to the bound-and-verify kernel / recomputed exactly
     void verify_counters(unsigned long long* pairs, unsigned long long* redone) const;

@@ -770,7 +770,8 @@ class CATrainer {
         const char* res_env = getenv("FR_LS_RESIDENT");
         if (fused_ && !(res_env && res_env[0] == '0')) {
             std::string _err;
-            if (dev.resident_reserve(R, &_err)) {
+            res_owner_ = dev.resident_reserve(R, &_err);
+            if (res_owner_ != 0) {
                 resident_ = true;
                 if (const char* e = getenv("FR_RESIDENT_REFRESH")) res_refresh_ = (uint32_t)std::max(1, atoi(e));
                 std::vector<size_t> all(R);
@@ -835,6 +836,7 @@ class CATrainer {
                     lg.candidates.assign(r.cands.begin() + c0, r.cands.begin() + std::min(r.cands.size(), c0 + 64));
                     if (resident_) {
                         lg.resident_slot = r.slot;
+                        lg.resident_owner = res_owner_;
                         lg.resident_norm = r.norm;
                         lg.resident_base_f = orig;
                         lg.resident_err = r.res_err;
@@ -965,7 +967,11 @@ class CATrainer {
             if (!dev.score_linear(bn, w.data(), &_err)) fail_str(_err);
             for (size_t k = 0; k < bn; k++) {
                 Restart& r = rs_[which[b0 + k]];
-                if (!dev.resident_store_from_scores((size_t)r.slot, k, &_err)) fail_str(_err);
+                if (!dev.resident_store_from_scores(res_owner_, (size_t)r.slot, k, &_err)) {
+                    if (!_err.empty()) fail_str(_err);
+                    resident_ = false;  // another trainer took the buffers over: form the sums from the tiles from now on
+                    return;
+                }
                 double T = 0.0;
                 for (size_t j = 0; j < d_; j++) T += std::fabs(r.best_w[j]) * X[j];
                 r.res_err = 1.1 * (double)(d_ + 1) * std::ldexp(1.0, -53) * T;  // gamma_D * T of an ordered sum
@@ -1016,6 +1022,7 @@ class CATrainer {
     bool fused_ = false;
     bool fullrank_ = false;
     bool resident_ = false;
+    uint64_t res_owner_ = 0;
     uint32_t res_refresh_ = 256;  // incremental updates of a resident sum between exact refreshes
     std::vector<Restart> rs_;
     std::vector<frdev::LineGroup> groups_;

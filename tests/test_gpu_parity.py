@@ -794,3 +794,29 @@ def test_trainer_variants_share_one_trajectory(small, env, monkeypatch):
         assert r["weights"] == exp_w[r["restart_id"]].tolist(), env
     assert shard["stats"]["useful_evals"] == int(exp_e.sum())
     assert shard["stats"]["ticks"] > 48, "several passes over the 24 features"
+
+
+def test_two_interleaved_trainers_on_one_dataset(small):
+    """Only one trainer can own a dataset's resident sums; the one that loses them must keep producing
+    the oracle's trajectory (it forms its sums from the tiles again)."""
+    X, y, qid, g, c = small
+    reqs = []
+    for seed in (21, 22):
+        req = fr.TrainRequest.coordinate_ascent()
+        req.measure = "ndcg@10"
+        req.params.seed, req.params.quiet, req.params.num_restarts, req.params.num_max_iterations = seed, True, 2, 5
+        reqs.append(req)
+    a = native.CoordinateAscentRun(g, reqs[0])
+    a.step(7)
+    b = native.CoordinateAscentRun(g, reqs[1])  # takes the resident buffers over
+    while not (a.finished and b.finished):
+        if not a.finished:
+            a.step(3)
+        if not b.finished:
+            b.step(5)
+    for run, req in ((a, reqs[0]), (b, reqs[1])):
+        exp_s, exp_w, _, err = c.ca_learn("ndcg@10", req.params.to_dict(), threads=2)
+        assert err == 0
+        for r in run.state()["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+        run.close()
