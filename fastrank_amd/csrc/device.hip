@@ -15,6 +15,7 @@
 //   kernels_verify.inc      linesearch_verify_kernel: bound-and-verify NDCG@k line search (the hot path; the exact
 //                           kernel recomputes the pairs it cannot verify)
 //   kernels_fullrank.inc    linesearch_scores_kernel + rank_metric_kernel: AP / RR / depth-less NDCG
+//   kernels_rr.inc          rr_verify_kernel / rr_exact_kernel: reciprocal rank by bound-and-verify
 //   device_dataset.inc      DeviceDataset: HBM layout (runs, tiles, tables) and every launcher
 #include "device.hpp"
 
@@ -39,6 +40,7 @@ namespace frdev {
 #include "kernels_linesearch.inc"
 #include "kernels_verify.inc"
 #include "kernels_fullrank.inc"
+#include "kernels_rr.inc"
 #include "device_dataset.inc"
 
 }  // namespace frdev

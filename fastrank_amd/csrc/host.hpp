@@ -768,7 +768,7 @@ class CATrainer {
         // R ~ sum_j x_j * best_w_j for every document, so a tick reads 24 bytes per document and restart instead
         // of the whole feature row.  FR_LS_RESIDENT=0 turns it off (every tick then forms the sums from the tiles).
         const char* res_env = getenv("FR_LS_RESIDENT");
-        if (fused_ && !(res_env && res_env[0] == '0')) {
+        if ((fused_ || (fullrank_ && ev_.measure == frdev::M_RR)) && !(res_env && res_env[0] == '0')) {
             std::string _err;
             res_owner_ = dev.resident_reserve(R, &_err);
             if (res_owner_ != 0) {
@@ -874,9 +874,17 @@ class CATrainer {
                     if (!r.done) r.pend = false;  // the device applied the pending updates of this tick's groups
         } else if (fullrank_) {
             std::string _err;
+            unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+            dev.verify_counters(&p0, &r0);
             if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_, &means_, &_err))
                 fail_str(_err);
+            dev.verify_counters(&p1, &r1);
+            stats_.verify_pairs += p1 - p0;
+            stats_.verify_redone += r1 - r0;
             check_flags(dev);
+            if (resident_)
+                for (Restart& r : rs_)
+                    if (!r.done) r.pend = false;  // applied by the device (reciprocal rank: kernels_rr.inc)
         } else {
             evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
         }

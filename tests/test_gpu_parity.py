@@ -820,3 +820,28 @@ def test_two_interleaved_trainers_on_one_dataset(small):
         for r in run.state()["restarts"]:
             assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
         run.close()
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_mrr_training_by_bound_and_verify(small, ties):
+    """Reciprocal rank trains through rr_verify_kernel on resident sums; ties and duplicated documents
+    force rr_exact_kernel.  Both must give the oracle's trajectory."""
+    X, y, qid, g, c = small
+    if ties:
+        X = np.round(X * 2).astype(np.float32)
+        X[1::2] = X[0::2][: len(X[1::2])]
+        g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "mrr"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 17, True, 2, 5
+    shard = native.train_model_shard(g, req, 0, 2)
+    st = shard["stats"]
+    assert st["path"] == "fused_fullrank" and st["verify_pairs"] > 0
+    if ties:
+        assert st["verify_redone"] > 0
+    exp_s, exp_w, exp_e, err = c.ca_learn("mrr", p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["useful_evals"] == int(exp_e.sum())
