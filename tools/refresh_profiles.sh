@@ -21,5 +21,6 @@ python tools/treebench.py --reps 5 2>&1 | tail -1 > "$OUT/${TAG}_treebench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_tree" -o p -- python tools/treebench.py --reps 5 --check 0 > "$OUT/kt_tree.log" 2>&1
 cp "$OUT"/kt_tree/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt_tree/*/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv"
 python tools/train_e2e.py 2>&1 | tail -1 > "$OUT/${TAG}_train_e2e_10k.json"
+python tools/train_e2e.py --measure mrr --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1 > "$OUT/${TAG}_train_mrr_30k.json"
 rm -rf "$OUT/kt" "$OUT/kt_tree"
 ls -la "$OUT"
