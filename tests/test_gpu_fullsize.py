@@ -102,3 +102,34 @@ def test_sampled_queries_match_the_oracle_at_full_size(big):
         _, vals = native.evaluate_dense(m, g, measure)
         exp, _ = c.metric_from_scores(measure, c.score_linear(bases[0]))
         assert np.array_equal(vals[pick], exp), (name, measure)
+
+
+def test_verify_path_equals_exact_kernel_at_full_size(big, monkeypatch):
+    """Bound-and-verify (default) against the exact kernel alone (FR_LS_EXACT=1) on the whole matrix:
+    every per-query NDCG@10 of every candidate, and a stretch of real training (resident sums, incremental
+    updates), must agree bit for bit."""
+    name, X, y, qid, g = big
+    rng = np.random.default_rng(103)
+    feats, bases, cands = _groups(rng, X.shape[1], 4)
+    means_v, pq_v = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands, per_query=True)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    req.params.seed, req.params.quiet, req.params.num_restarts = 5, True, 4
+    run = native.CoordinateAscentRun(g, req)
+    run.step(25)
+    st_v = run.state()
+    run.close()
+    assert st_v["stats"]["verify_pairs"] > 0
+    monkeypatch.setenv("FR_LS_EXACT", "1")
+    means_e, pq_e = native.evaluate_candidates(g, "ndcg@10", feats, bases, cands, per_query=True)
+    run = native.CoordinateAscentRun(g, req)
+    run.step(25)
+    st_e = run.state()
+    run.close()
+    assert st_e["stats"]["verify_pairs"] == 0
+    for gi in range(4):  # (columns beyond a group's 51 candidates are not defined)
+        assert np.array_equal(pq_v[:, gi * 64: gi * 64 + 51], pq_e[:, gi * 64: gi * 64 + 51])
+    for a, b in zip(means_v, means_e):
+        assert np.array_equal(a, b)
+    assert st_v["restarts"] == st_e["restarts"]
+    assert st_v["stats"]["useful_evals"] == st_e["stats"]["useful_evals"]
