@@ -845,3 +845,19 @@ def test_mrr_training_by_bound_and_verify(small, ties):
     for r in shard["restarts"]:
         assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
     assert st["useful_evals"] == int(exp_e.sum())
+
+
+@pytest.mark.parametrize("measure", ["ndcg@3", "ndcg@20", "ndcg@1"])
+def test_resident_training_other_depths(small, measure):
+    X, y, qid, g, c = small
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = measure
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 23, True, 2, 4
+    shard = native.train_model_shard(g, req, 0, 2)
+    assert shard["stats"]["path"] == "fused_linesearch" and shard["stats"]["verify_pairs"] > 0
+    exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert shard["stats"]["useful_evals"] == int(exp_e.sum())
