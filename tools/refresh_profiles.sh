@@ -22,5 +22,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_tree" -o p -- p
 cp "$OUT"/kt_tree/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt_tree/*/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv"
 python tools/train_e2e.py 2>&1 | tail -1 > "$OUT/${TAG}_train_e2e_10k.json"
 python tools/train_e2e.py --measure mrr --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1 > "$OUT/${TAG}_train_mrr_30k.json"
+{ python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; FR_LS_EXACT=1 python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; } > "$OUT/${TAG}_train_e2e_30k.json"
 rm -rf "$OUT/kt" "$OUT/kt_tree"
 ls -la "$OUT"

@@ -2,6 +2,7 @@
 """End-to-end train_model to convergence on a synthetic MSLR shape (BASELINE.json configs[1]):
 wall time, ticks, useful/raw evaluations, final NDCG@10."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -49,7 +50,9 @@ def main():
                       "ticks": ticks, "train_wall_s": wall, "upload_init_s": t_init,
                       "useful_evals": st["stats"]["useful_evals"], "raw_evals": st["stats"]["raw_evals"],
                       "useful_evals_per_s": st["stats"]["useful_evals"] / wall, "final_mean": mean,
-                      "path": st["stats"]["path"]}))
+                      "path": st["stats"]["path"], "verify_pairs": st["stats"].get("verify_pairs"),
+                      "verify_redone": st["stats"].get("verify_redone"),
+                      "restarts_sha1": hashlib.sha1(json.dumps(st["restarts"], sort_keys=True).encode()).hexdigest()}))
 
 
 if __name__ == "__main__":
