@@ -259,6 +259,12 @@ def main():
                 traffic = json.load(open(tpath)).get(args.shape, {}).get(dom + "_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu_insts = None
+        if os.path.exists(tpath):
+            try:
+                valu_insts = json.load(open(tpath)).get(args.shape, {}).get(dom + "_valu_insts_per_launch")
+            except Exception:
+                valu_insts = None
         vstats = st.get("stats", {})
         vp, vr = float(vstats.get("verify_pairs", 0)), float(vstats.get("verify_redone", 0))
         # FP64 adds the exact ordered dot products would need (what the exact kernel is bound by)
@@ -302,9 +308,16 @@ def main():
             },
             "limiter": ({
                 "bound": "valu_issue",
-                "note": "bound-and-verify kernel: 2*D FMAs per document and group, then a per-document "
-                        "loop over the tile in candidate lanes (LDS broadcast, FMA, compare; min/max chain for "
-                        "documents that enter a list); VALU-issue bound, see DESIGN.md section 4",
+                # wave-level VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/hbm_traffic.json) over the
+                # HIP-event launch time, against 1024 SIMDs x one VALU instruction per 4 cycles at 2.4 GHz
+                "achieved": (valu_insts / avg_s / 1e9) if (valu_insts and avg_s > 0) else None,
+                "peak": 1024 * 2.4e9 / 4 / 1e9,
+                "unit": "G wave-instr/s",
+                "frac": (valu_insts / avg_s / (1024 * 2.4e9 / 4)) if (valu_insts and avg_s > 0) else None,
+                "note": "bound-and-verify kernel on resident sums: three operations per document and restart for the "
+                        "base dot product, then a per-document loop over the tile in candidate lanes (LDS broadcast, "
+                        "FMA, compare; min/max chain for documents that enter a list); VALU-issue bound, "
+                        "see DESIGN.md section 4",
                 "verify_pairs": vp,
                 "verify_redone": vr,
                 "redo_fraction": (vr / vp) if vp else None,
