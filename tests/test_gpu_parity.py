@@ -861,3 +861,16 @@ def test_resident_training_other_depths(small, measure):
     for r in shard["restarts"]:
         assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
     assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+
+
+def test_randomised_parity_soak():
+    """tools/fuzz_parity.py: random small datasets (ties, duplicates, integer columns, negative gains, long and
+    one-document queries), random parameters and measures; every restart must equal the oracle's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--iters", "80", "--seed", "7"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    last = out.stdout.strip().splitlines()[-1]
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert json.loads(last)["mismatches"] == 0
