@@ -66,10 +66,17 @@ def main():
     rng = np.random.default_rng(args.seed)
     o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
     t0 = time.time()
-    paths, redone, bad = {}, 0, 0
+    paths, redone, bad, sampled = {}, 0, 0, 0
     for it in range(args.iters):
         X, y, qid, measure, params = make_case(rng)
-        g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+        g = fr.CDataset.from_numpy(X, y, qid)
+        if rng.random() < 0.3 and len(np.unique(qid)) > 2:  # a query-sampled view (train/test split style)
+            keep = rng.choice(np.unique(qid), size=max(1, len(np.unique(qid)) // 2), replace=False)
+            g = g.subsample_queries([str(int(q)) for q in keep])
+            mask = np.isin(qid, keep)
+            X, y, qid = np.ascontiguousarray(X[mask]), np.ascontiguousarray(y[mask]), np.ascontiguousarray(qid[mask])
+            sampled += 1
+        c = o.Dataset(X, y, qid)
         req = fr.TrainRequest.coordinate_ascent()
         req.measure = measure
         req.params = fr.CoordinateAscentParams(**params)
@@ -91,7 +98,7 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH iter", it, json.dumps({"n": len(y), "d": X.shape[1], "measure": measure, "params": params, "oracle_err": err}))
-    print(json.dumps({"iters": args.iters, "mismatches": bad, "paths": paths, "verify_redone": int(redone),
+    print(json.dumps({"iters": args.iters, "mismatches": bad, "paths": paths, "verify_redone": int(redone), "sampled_views": sampled,
                       "seconds": round(time.time() - t0, 1)}))
     return 1 if bad else 0
 
