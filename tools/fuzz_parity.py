@@ -95,6 +95,13 @@ def main():
         ok = err == 0 and st["useful_evals"] == int(exp_e.sum())
         for r in shard["restarts"]:
             ok = ok and r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+        if ok:  # the trained model through the reference API: scores and per-query metric
+            best = exp_w[o.select_best(exp_s)]
+            model = fr.CModel.from_dict({"Linear": {"weights": best.tolist()}})
+            scores = c.score_linear(best)
+            exp_pq, e2 = c.metric_from_scores(measure, scores)
+            got = g.evaluate(model, measure)
+            ok = e2 == 0 and got == dict(zip((str(int(q)) for q in c.query_ids()), exp_pq.tolist()))
         if not ok:
             bad += 1
             print("MISMATCH iter", it, json.dumps({"n": len(y), "d": X.shape[1], "measure": measure, "params": params, "oracle_err": err}))
