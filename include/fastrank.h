@@ -139,7 +139,9 @@ void fr_ca_free(void *trainer);
  * restarts_json: JSON list of {"restart_id","score","weights"}; returns a CModel. */
 const CResult *fr_select_model(const void *restarts_json, int output_ensemble);
 /* JSON stats of the most recent train_model / fr_train_model_shard call in this process:
- * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts"}. */
+ * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts","verify_pairs","verify_redone"}
+ * (path: "fused_linesearch" | "fused_fullrank" | "generic_sort"; verify_*: (query, group) pairs evaluated by the
+ * bound-and-verify kernels and how many of them were recomputed by the exact kernels). */
 const void *fr_last_train_stats(void);
 
 /* Dense results without JSON.  out[i] = score of instance i (instances outside the dataset
