@@ -77,7 +77,7 @@ def gen_mslr_shaped(seed, n, d, q):
     return X, y, qid
 
 
-def cpu_baseline(X, y, qid, params, target_seconds):
+def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
     """Times oracle/ (the C restatement of the reference algorithm; kind="port") on the host
     cores: threads over restarts only, like rayon in the reference.  Bounded sample."""
     from oracle import pyoracle as o
@@ -90,7 +90,7 @@ def cpu_baseline(X, y, qid, params, target_seconds):
 
     def run(max_evals):
         t0 = time.perf_counter()
-        _, _, evals, _ = ds.ca_learn("ndcg@10", p, threads=threads, max_evals_per_restart=max_evals)
+        _, _, evals, _ = ds.ca_learn(measure, p, threads=threads, max_evals_per_restart=max_evals)
         return int(evals.sum()), time.perf_counter() - t0
 
     n1, t1 = run(2)
@@ -114,6 +114,7 @@ def cpu_baseline(X, y, qid, params, target_seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--measure", default="ndcg@10", help="headline = ndcg@10 (BASELINE.json); others (ndcg, map, mrr, ndcg@k) for side measurements")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shape", default=os.environ.get("FR_BENCH_SHAPE", "30k"), choices=sorted(SHAPES))
@@ -156,7 +157,7 @@ def main():
 
     R = args.restarts_per_gpu * world
     req = fr.TrainRequest.coordinate_ascent()
-    req.measure = "ndcg@10"
+    req.measure = args.measure
     p = req.params
     p.num_restarts, p.num_max_iterations, p.step_base, p.step_scale = R, 25, 0.05, 2.0
     p.tolerance, p.normalize, p.init_random, p.seed, p.quiet = 0.001, True, True, 42, True
@@ -246,7 +247,8 @@ def main():
         b_eval = n * (4 * d + 8)  # algorithmic bytes per evaluate_mean
         # dominant kernel: the bound-and-verify line search (the exact kernel only recomputes the pairs it
         # could not verify); FR_LS_EXACT=1 runs measure the exact kernel instead
-        dom = "linesearch_verify_kernel" if "linesearch_verify_kernel" in prof else "linesearch_ndcg_kernel"
+        dom = next((k for k in ("linesearch_verify_kernel", "rr_verify_kernel", "rank_metric_kernel") if k in prof),
+                   "linesearch_ndcg_kernel")
         ls = prof.get(dom, {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
         exact = prof.get("linesearch_ndcg_kernel", {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
         evals_per_launch = (raw / max(1, ls["launches"])) if ls["launches"] else 0.0
@@ -270,7 +272,8 @@ def main():
         # FP64 adds the exact ordered dot products would need (what the exact kernel is bound by)
         adds_per_launch = n * args.restarts_per_gpu * 51 * (d - 1) / 2.0  # avg shared prefix = half the features
         out = {
-            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape",
+            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape" if args.measure == "ndcg@10"
+            else "coordinate-ascent {} evals/sec on MSLR-WEB30K shape (side measurement)".format(args.measure),
             "value": useful_all / elapsed_max,
             "unit": "evals/s",
             "n_gpus": world,
@@ -284,8 +287,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic MSLR-WEB{} shape: {} docs x {} features x {} queries, coordinate ascent "
-                            "NDCG@10, {} restarts/GPU x 25 steps/coord (configs[2])".format(
-                                args.shape.upper(), n, d, q, args.restarts_per_gpu),
+                            "{}, {} restarts/GPU x 25 steps/coord (configs[2])".format(
+                                args.shape.upper(), n, d, q, args.measure.upper() if args.measure.startswith("ndcg") else args.measure, args.restarts_per_gpu),
                 "restarts_total": R,
                 "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
                 "evals_per_step_per_gpu": evals_per_launch,
@@ -336,7 +339,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             del run
-            out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds, args.measure)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
