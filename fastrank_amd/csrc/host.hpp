@@ -14,6 +14,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -358,38 +359,50 @@ struct DatasetView {
     void build_csr() {
         if (csr_built) return;
         const DataCore& c = *core;
-        std::unordered_map<uint32_t, uint32_t> slot;  // core query index -> CSR query
-        std::vector<std::vector<uint32_t>> groups;
+        for (uint32_t id : instances)  // (the reference panics on a NaN label: src/dense_dataset.rs:114-123)
+            if (c.gain[id] != c.gain[id]) fail_str("NaN in ys[" + std::to_string(id) + "]");
+        // queries in first-appearance order over this view's instances (counting pass, then fill)
+        std::vector<int32_t> slot(c.qnames.size(), -1);  // core query index -> CSR query
+        std::vector<uint32_t> count;
         for (uint32_t id : instances) {
-            uint32_t qi = c.qix[id];
-            auto it = slot.find(qi);
-            if (it == slot.end()) {
-                it = slot.emplace(qi, (uint32_t)groups.size()).first;
-                groups.emplace_back();
+            const uint32_t qi = c.qix[id];
+            if (slot[qi] < 0) {
+                slot[qi] = (int32_t)count.size();
+                count.push_back(0);
                 csr_query.push_back(qi);
             }
-            groups[it->second].push_back(id);
+            count[(size_t)slot[qi]]++;
         }
         csr.n = instances.size();
         csr.d = c.d;
-        csr.nq = groups.size();
+        csr.nq = count.size();
         csr.x = c.x;
-        csr.perm.reserve(csr.n);
-        csr.gain.reserve(csr.n);
-        csr.qoff.assign(1, 0);
-        for (auto& g : groups) {
-            // reverse tie-break layout: gain desc, instance id desc (device.hpp header comment)
-            std::sort(g.begin(), g.end(), [&](uint32_t a, uint32_t b) {
-                float ga = c.gain[a], gb = c.gain[b];
-                if (ga != gb) return ga > gb;
-                return a > b;
-            });
-            for (uint32_t id : g) {
-                csr.perm.push_back(id);
-                csr.gain.push_back(c.gain[id]);
-            }
-            csr.qoff.push_back((uint32_t)csr.perm.size());
+        csr.qoff.assign(csr.nq + 1, 0);
+        for (size_t q = 0; q < csr.nq; q++) csr.qoff[q + 1] = csr.qoff[q] + count[q];
+        csr.perm.assign(csr.n, 0);
+        {
+            std::vector<uint32_t> fill(csr.qoff.begin(), csr.qoff.end() - 1);
+            for (uint32_t id : instances) csr.perm[fill[(size_t)slot[c.qix[id]]]++] = id;
         }
+        // reverse tie-break layout inside each query: gain desc, instance id desc (device.hpp header comment)
+        {
+            unsigned hw = std::thread::hardware_concurrency();
+            const size_t nthreads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, csr.n > 200000 ? 16 : 1));
+            auto work = [&](size_t tid) {
+                for (size_t q = tid; q < csr.nq; q += nthreads)
+                    std::sort(csr.perm.begin() + csr.qoff[q], csr.perm.begin() + csr.qoff[q + 1], [&](uint32_t a2, uint32_t b2) {
+                        const float ga = c.gain[a2], gb = c.gain[b2];
+                        if (ga != gb) return ga > gb;
+                        return a2 > b2;
+                    });
+            };
+            std::vector<std::thread> pool;
+            for (size_t tid = 1; tid < nthreads; tid++) pool.emplace_back(work, tid);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
+        csr.gain.resize(csr.n);
+        for (size_t p = 0; p < csr.n; p++) csr.gain[p] = c.gain[csr.perm[p]];
         csr_built = true;
     }
 
