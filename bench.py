@@ -208,6 +208,21 @@ def main():
     native.profile_enable(False)
     s1 = dict(totals)
     prof = native.profile_stats()
+    # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
+    # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
+    # step, nothing else on the device) give the duration of an isolated launch; they are not part of `value`.
+    iso = None
+    if not os.environ.get("FR_LS_PIPELINE"):
+        os.environ["FR_LS_PIPELINE"] = "0"
+        try:
+            native.profile_reset()
+            native.profile_enable(True)
+            advance(min(5, args.steps))
+            torch.cuda.synchronize()
+            native.profile_enable(False)
+            iso = native.profile_stats()
+        finally:
+            del os.environ["FR_LS_PIPELINE"]
 
     useful = s1["useful_evals"] - s0["useful_evals"]
     raw = s1["raw_evals"] - s0["raw_evals"]
@@ -254,19 +269,23 @@ def main():
         evals_per_launch = (raw / max(1, ls["launches"])) if ls["launches"] else 0.0
         avg_s = ls["avg_ms"] * 1e-3
         achieved = (b_eval * evals_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0
+        # The PMC figures of profiles/hbm_traffic.json were collected on launches of `pmc_groups` line groups
+        # (one per restart); the trainer steps the restarts as two halves (two launches per step, one in flight
+        # while the host handles the other), so a launch here carries groups_per_launch of them.
         traffic = None
+        valu_insts = None
+        groups_per_launch = evals_per_launch / 51.0
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.shape, {}).get(dom + "_bytes_per_launch")
+                tj = json.load(open(tpath)).get(args.shape, {})
+                scale = groups_per_launch / float(tj.get("pmc_groups_per_launch", 32))
+                traffic = tj.get(dom + "_bytes_per_launch")
+                traffic = traffic * scale if traffic else None
+                valu_insts = tj.get(dom + "_valu_insts_per_launch")
+                valu_insts = valu_insts * scale if valu_insts else None
             except Exception:
-                traffic = None
-        valu_insts = None
-        if os.path.exists(tpath):
-            try:
-                valu_insts = json.load(open(tpath)).get(args.shape, {}).get(dom + "_valu_insts_per_launch")
-            except Exception:
-                valu_insts = None
+                traffic = valu_insts = None
         vstats = st.get("stats", {})
         vp, vr = float(vstats.get("verify_pairs", 0)), float(vstats.get("verify_redone", 0))
         # FP64 adds the exact ordered dot products would need (what the exact kernel is bound by)
@@ -291,7 +310,9 @@ def main():
                                 args.shape.upper(), n, d, q, args.measure.upper() if args.measure.startswith("ndcg") else args.measure, args.restarts_per_gpu),
                 "restarts_total": R,
                 "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
-                "evals_per_step_per_gpu": evals_per_launch,
+                "evals_per_step_per_gpu": raw / max(1, args.steps),
+                "launches_per_step": ls["launches"] / max(1, args.steps),
+                "groups_per_launch": groups_per_launch,
             },
             "raw_evals_per_s": raw_all / elapsed_max,
             "useful_fraction": useful_all / max(1.0, raw_all),
@@ -307,16 +328,35 @@ def main():
                 "launches": ls["launches"],
                 "algorithmic_bytes_per_launch": b_eval * evals_per_launch,
                 "note": "batched: one pass over X serves every candidate of a launch, so the algorithmic "
-                        "(per-eval) bytes exceed real HBM traffic and frac can exceed 1; see limiter",
+                        "(per-eval) bytes exceed real HBM traffic and frac can exceed 1; see limiter.  Launches of "
+                        "the timed region overlap (three streams): avg_launch_ms includes time shared with the "
+                        "neighbouring launches",
             },
             "limiter": ({
                 "bound": "valu_issue",
-                # wave-level VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/hbm_traffic.json) over the
-                # HIP-event launch time, against 1024 SIMDs x one VALU instruction per 4 cycles at 2.4 GHz
-                "achieved": (valu_insts / avg_s / 1e9) if (valu_insts and avg_s > 0) else None,
+                # wave-level VALU instructions of the dominant kernel (rocprofv3 SQ_INSTS_VALU per (run, group) pair,
+                # profiles/hbm_traffic.json, first ticks of a run) issued over the WHOLE timed region -- launch gaps,
+                # the small kernels and the host's share included -- against 1024 SIMDs x one VALU instruction per
+                # 4 cycles at 2.4 GHz.  The timed launches overlap at their ends (three streams), so their own
+                # HIP-event durations (per_launch_overlapped) add up to more than the elapsed time; isolated_launch
+                # is the same kernel alone on the device.
+                "achieved": (valu_insts * ls["launches"] / elapsed_max / 1e9) if valu_insts else None,
                 "peak": 1024 * 2.4e9 / 4 / 1e9,
                 "unit": "G wave-instr/s",
-                "frac": (valu_insts / avg_s / (1024 * 2.4e9 / 4)) if (valu_insts and avg_s > 0) else None,
+                "frac": (valu_insts * ls["launches"] / elapsed_max / (1024 * 2.4e9 / 4)) if valu_insts else None,
+                "per_launch_overlapped": {
+                    "avg_launch_ms": ls["avg_ms"],
+                    "groups_per_launch": groups_per_launch,
+                    "frac": (valu_insts / avg_s / (1024 * 2.4e9 / 4)) if (valu_insts and avg_s > 0) else None,
+                },
+                "isolated_launch": ({
+                    "avg_launch_ms": iso[dom]["avg_ms"],
+                    "launches": iso[dom]["launches"],
+                    "groups_per_launch": args.restarts_per_gpu,
+                    "frac": (valu_insts / groups_per_launch * args.restarts_per_gpu / (iso[dom]["avg_ms"] * 1e-3)
+                             / (1024 * 2.4e9 / 4)) if (valu_insts and iso[dom]["avg_ms"] > 0) else None,
+                    "note": "lock-step steps after the timed region (FR_LS_PIPELINE=0): one launch per step, no overlap",
+                } if (iso and dom in iso) else None),
                 "note": "bound-and-verify kernel on resident sums: three operations per document and restart for the "
                         "base dot product, then a per-document loop over the tile in candidate lanes (LDS broadcast, "
                         "FMA, compare; min/max chain for documents that enter a list); VALU-issue bound, "

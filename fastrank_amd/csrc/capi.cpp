@@ -238,7 +238,7 @@ fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
     if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
     fr::CATrainer trainer(view, std::move(ev), rq.ca, rbegin, rend);
-    while (trainer.tick()) {
+    while (trainer.run(64, nullptr)) {
     }
     std::vector<fr::RestartResult> hist = trainer.results();
     trainer.stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -706,8 +706,7 @@ const void* fr_ca_step(void* trainer, uint64_t max_ticks, uint64_t* ticks_done, 
         FrTrainer* h = (FrTrainer*)trainer;
         std::lock_guard<std::mutex> lk(g_api_mu);
         uint64_t n = 0;
-        bool alive = true;
-        while (n < max_ticks && (alive = h->t->tick())) n++;
+        const bool alive = h->t->run(max_ticks, &n);
         if (ticks_done) *ticks_done = n;
         if (finished) *finished = (!alive || h->t->done()) ? 1 : 0;
     });

@@ -113,6 +113,13 @@ class DeviceDataset {
     // evaluates every candidate of every group; means[g*64 + c]
     bool linesearch_ndcg(int64_t depth, const double* norms, const std::vector<LineGroup>& groups,
                          std::vector<double>* means, std::string* err);
+    // The same in parts, for callers that keep several independent sets of groups in flight (ctx 0 ..
+    // LINESEARCH_CONTEXTS-1: each has its own stream and buffers, so the host's work between two line searches of
+    // one set overlaps the kernels of the others).  submit queues everything and returns; collect waits and
+    // returns means[g*64 + c].
+    static constexpr int LINESEARCH_CONTEXTS = 4;
+    bool linesearch_ndcg_submit(int ctx, int64_t depth, const double* norms, const std::vector<LineGroup>& groups, std::string* err);
+    bool linesearch_ndcg_collect(int ctx, std::vector<double>* means, std::string* err);
     // resident per-document sums for LineGroup::resident_slot: `slots` double-buffered arrays of np doubles
     // Returns an owner ticket (0 on failure).  A later reserve by someone else takes the buffers over: groups
     // and stores that carry the old ticket are then treated as non-resident / refused.

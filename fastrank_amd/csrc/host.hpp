@@ -753,7 +753,6 @@ class CATrainer {
         stats_.path = fused_ ? "fused_linesearch" : (fullrank_ ? "fused_fullrank" : "generic_sort");
         stats_.restarts = (uint32_t)rs_.size();
         if (rs_.empty()) return;
-
         // initial weights + initial evaluate_mean (:104-111)
         const size_t R = rs_.size();
         std::vector<double> w0(R * d_, 0.0);
@@ -806,18 +805,137 @@ class CATrainer {
     // One lock-step tick.  Returns false when every restart had already converged.
     bool tick() {
         frdev::DeviceDataset& dev = view_->device();
-        groups_.clear();
+        size_t gen_B = 0;
+        if (!build_groups(-1, groups_, &gen_B)) return false;
+        dev.set_sums_only((bool)shard_.allreduce);  // the dataset object may be shared with other callers
+        if (fused_) {
+            std::string _err;
+            unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+            dev.verify_counters(&p0, &r0);
+            if (!dev.linesearch_ndcg(ev_.depth, ev_.norms.data(), groups_, &means_, &_err)) fail_str(_err);
+            dev.verify_counters(&p1, &r1);
+            stats_.verify_pairs += p1 - p0;
+            stats_.verify_redone += r1 - r0;
+            check_flags(dev);
+        } else if (fullrank_) {
+            std::string _err;
+            unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+            dev.verify_counters(&p0, &r0);
+            if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_, &means_, &_err))
+                fail_str(_err);
+            dev.verify_counters(&p1, &r1);
+            stats_.verify_pairs += p1 - p0;
+            stats_.verify_redone += r1 - r0;
+            check_flags(dev);
+        } else {
+            evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
+        }
+        global_means(means_);
+        stats_.ticks++;
+        stats_.groups += (fused_ || fullrank_) ? groups_.size() : gen_B;
+        apply_results(-1, means_);
+        return true;
+    }
+
+    // Up to max_ticks lock-step ticks; *ticks_done = how many happened.  Returns false when every restart had
+    // already converged before the last of them.  On the fused NDCG@k path the restarts are stepped as a few
+    // sets with one line search of each in flight (DeviceDataset::linesearch_ndcg_submit): while the host
+    // replays the accept logic of one set and stages its next tick, the device works on the others.  A
+    // restart's trajectory does not depend on what it is batched with, so the results are the same as tick()'s;
+    // every submitted line search is collected and applied before this returns.
+    bool run(uint64_t max_ticks, uint64_t* ticks_done) {
+        uint64_t n = 0;
+        bool alive = true;
+        {  // how many sets this call keeps in flight (FR_LS_PIPELINE=n; 0 or 1: plain lock step); read per call
+            const char* pe = getenv("FR_LS_PIPELINE");
+            long want = pe ? atol(pe) : 3;
+            want = std::min<long>(want, frdev::DeviceDataset::LINESEARCH_CONTEXTS);
+            want = std::min<long>(want, (long)rs_.size());
+            parts_ = (fused_ && !shard_.allreduce && want >= 2) ? (int)want : 1;
+        }
+        if (parts_ < 2) {
+            while (n < max_ticks && (alive = tick())) n++;
+            if (ticks_done) *ticks_done = n;
+            return alive;
+        }
+        frdev::DeviceDataset& dev = view_->device();
+        constexpr int MAXP = frdev::DeviceDataset::LINESEARCH_CONTEXTS;
+        uint64_t steps[MAXP] = {};
+        bool inflight[MAXP] = {};
+        auto submit = [&](int h) {
+            size_t unused = 0;
+            if (steps[h] >= max_ticks || !build_groups(h, groups_h_[h], &unused)) return;
+            dev.set_sums_only(false);
+            std::string _err;
+            if (!dev.linesearch_ndcg_submit(h, ev_.depth, ev_.norms.data(), groups_h_[h], &_err)) fail_str(_err);
+            inflight[h] = true;
+        };
+        auto drain = [&]() {  // an error is on its way out: leave no submitted line search behind
+            for (int h = 0; h < parts_; h++)
+                if (inflight[h]) {
+                    std::string _e;
+                    std::vector<double> tmp;
+                    (void)dev.linesearch_ndcg_collect(h, &tmp, &_e);
+                    inflight[h] = false;
+                }
+        };
+        try {
+            for (int h = 0; h < parts_; h++) submit(h);
+            for (bool any = true; any;) {
+                any = false;
+                for (int h = 0; h < parts_; h++) {
+                    if (!inflight[h]) continue;
+                    any = true;
+                    std::string _err;
+                    unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+                    dev.verify_counters(&p0, &r0);
+                    inflight[h] = false;
+                    if (!dev.linesearch_ndcg_collect(h, &means_h_[h], &_err)) fail_str(_err);
+                    dev.verify_counters(&p1, &r1);
+                    stats_.verify_pairs += p1 - p0;
+                    stats_.verify_redone += r1 - r0;
+                    check_flags(dev);
+                    stats_.groups += groups_h_[h].size();
+                    apply_results(h, means_h_[h]);
+                    steps[h]++;
+                    submit(h);
+                }
+            }
+        } catch (...) {
+            drain();
+            throw;
+        }
+        for (int h = 0; h < parts_; h++) n = std::max(n, steps[h]);
+        stats_.ticks += n;
+        if (ticks_done) *ticks_done = n;
+        return n == max_ticks;
+    }
+
+  private:
+    // part -1: every restart; otherwise the part-th of run()'s parts_ contiguous sets
+    bool in_part(size_t k, int part) const {
+        if (part < 0) return true;
+        const size_t R = rs_.size(), P = (size_t)parts_;
+        return k >= R * (size_t)part / P && k < R * ((size_t)part + 1) / P;
+    }
+
+    // Stages the next line search of every live restart of the half: shuffles at the start of a pass
+    // (coordinate_ascent.rs:113-116), normalises (:131-143), lists the candidates (:145-171).  Returns false when
+    // the half has no live restart.
+    bool build_groups(int part, std::vector<frdev::LineGroup>& groups, size_t* gen_B_out) {
+        groups.clear();
         gen_w_.clear();
         size_t gen_B = 0;
         bool any = false;
         if (resident_) {
             std::vector<size_t> stale;
             for (size_t k = 0; k < rs_.size(); k++)
-                if (!rs_[k].done && rs_[k].res_updates >= res_refresh_) stale.push_back(k);
+                if (in_part(k, part) && !rs_[k].done && rs_[k].res_updates >= res_refresh_) stale.push_back(k);
             if (!stale.empty()) refresh_resident(stale);
         }
-        for (Restart& r : rs_) {
-            if (r.done) continue;
+        for (size_t k = 0; k < rs_.size(); k++) {
+            Restart& r = rs_[k];
+            if (r.done || !in_part(k, part)) continue;
             any = true;
             if (r.pos == 0 && r.order.empty()) {
                 r.order = fids_;
@@ -841,7 +959,7 @@ class CATrainer {
             double orig = r.base[f];
             line_candidates(orig, p_, r.cands, r.block_len);
             if (fused_ || fullrank_) {
-                r.first_group = groups_.size();
+                r.first_group = groups.size();
                 for (size_t c0 = 0; c0 < r.cands.size(); c0 += 64) {
                     frdev::LineGroup lg;
                     lg.feature = f;
@@ -859,8 +977,11 @@ class CATrainer {
                         lg.upd_base_f = r.pend_base_f;
                         lg.upd_cand = r.pend_cand;
                     }
-                    groups_.push_back(std::move(lg));
+                    groups.push_back(std::move(lg));
                 }
+                // the device applies the pending update of this restart with the line search staged here (the verify
+                // kernel, or resident_update_kernel when the exact kernels run instead)
+                if (resident_) r.pend = false;
             } else {
                 r.first_group = gen_B;
                 for (double cw : r.cands) {
@@ -871,49 +992,23 @@ class CATrainer {
                 }
             }
         }
-        if (!any) return false;
-        dev.set_sums_only((bool)shard_.allreduce);  // the dataset object may be shared with other callers
-        if (fused_) {
-            std::string _err;
-            unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
-            dev.verify_counters(&p0, &r0);
-            if (!dev.linesearch_ndcg(ev_.depth, ev_.norms.data(), groups_, &means_, &_err)) fail_str(_err);
-            dev.verify_counters(&p1, &r1);
-            stats_.verify_pairs += p1 - p0;
-            stats_.verify_redone += r1 - r0;
-            check_flags(dev);
-            if (resident_)
-                for (Restart& r : rs_)
-                    if (!r.done) r.pend = false;  // the device applied the pending updates of this tick's groups
-        } else if (fullrank_) {
-            std::string _err;
-            unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
-            dev.verify_counters(&p0, &r0);
-            if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_, &means_, &_err))
-                fail_str(_err);
-            dev.verify_counters(&p1, &r1);
-            stats_.verify_pairs += p1 - p0;
-            stats_.verify_redone += r1 - r0;
-            check_flags(dev);
-            if (resident_)
-                for (Restart& r : rs_)
-                    if (!r.done) r.pend = false;  // applied by the device (reciprocal rank: kernels_rr.inc)
-        } else {
-            evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
-        }
-        global_means(means_);
-        stats_.ticks++;
-        stats_.groups += (fused_ || fullrank_) ? groups_.size() : gen_B;
-        for (Restart& r : rs_) {
-            if (r.done) continue;
+        *gen_B_out = gen_B;
+        return any;
+    }
+
+    // Replays coordinate_ascent.rs:145-186 over the batched results of the half's line searches.
+    void apply_results(int part, const std::vector<double>& means) {
+        frdev::DeviceDataset& dev = view_->device();
+        for (size_t k = 0; k < rs_.size(); k++) {
+            Restart& r = rs_[k];
+            if (r.done || !in_part(k, part)) continue;
             uint32_t f = r.order[r.pos];
-            // replay coordinate_ascent.rs:145-176 over the batched results
             size_t c = 0;
             long accepted = -1;  // index of the last accepted candidate of this line search
             for (int s = 0; s < 3; s++) {
                 for (uint32_t it = 0; it < r.block_len[s]; it++, c++) {
-                    double sc = (fused_ || fullrank_) ? means_[(r.first_group + c / 64) * 64 + (c % 64)]
-                                                      : means_[r.first_group + c];
+                    double sc = (fused_ || fullrank_) ? means[(r.first_group + c / 64) * 64 + (c % 64)]
+                                                      : means[r.first_group + c];
                     stats_.useful_evals++;
                     if (sc == sc && sc > r.best_score) {  // core.rs:57-66: NaN rejected, strict >
                         r.best_score = sc;
@@ -954,9 +1049,9 @@ class CATrainer {
                 }
             }
         }
-        return true;
     }
 
+  public:
     std::vector<RestartResult> results() const {
         std::vector<RestartResult> out;
         for (const Restart& r : rs_) {
@@ -1046,7 +1141,9 @@ class CATrainer {
     uint64_t res_owner_ = 0;
     uint32_t res_refresh_ = 256;  // incremental updates of a resident sum between exact refreshes
     std::vector<Restart> rs_;
-    std::vector<frdev::LineGroup> groups_;
+    std::vector<frdev::LineGroup> groups_, groups_h_[frdev::DeviceDataset::LINESEARCH_CONTEXTS];
+    std::vector<double> means_h_[frdev::DeviceDataset::LINESEARCH_CONTEXTS];
+    int parts_ = 1;  // sets of restarts run() keeps in flight
     std::vector<double> gen_w_, means_;
     TrainStats stats_;
 };

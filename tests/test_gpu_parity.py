@@ -796,6 +796,43 @@ def test_trainer_variants_share_one_trajectory(small, env, monkeypatch):
     assert shard["stats"]["ticks"] > 48, "several passes over the 24 features"
 
 
+@pytest.mark.parametrize("parts", ["0", "2", "3", "4"])
+def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, parts, monkeypatch):
+    """fr_ca_step keeps one line search of each of a few sets of restarts in flight (FR_LS_PIPELINE sets, default
+    3; 0 = plain lock step).  Whatever the split and however the ticks are chunked into calls, every restart
+    follows the oracle's trajectory and the counters agree with lock step."""
+    X, y, qid, g, c = small
+    monkeypatch.setenv("FR_LS_PIPELINE", parts)
+    monkeypatch.setenv("FR_RESIDENT_REFRESH", "3")  # exact refreshes on the main stream between pipelined ticks
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 17, True, 7, 5
+    run = native.CoordinateAscentRun(g, req)
+    chunks = [1, 2, 5, 1, 3, 11, 64]
+    ticks = 0
+    k = 0
+    while not run.finished:
+        ticks += run.step(chunks[k % len(chunks)])
+        k += 1
+        assert len(run.state()["restarts"]) == 7  # a consistent state between calls: nothing left in flight
+    st = run.state()
+    run.close()
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=4)
+    assert err == 0
+    for r in st["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]], parts
+        assert r["weights"] == exp_w[r["restart_id"]].tolist(), parts
+    assert st["stats"]["useful_evals"] == int(exp_e.sum())
+    assert st["stats"]["ticks"] == ticks
+    # every restart runs whole passes over the 24 features, so the longest-lived one fixes the tick count
+    monkeypatch.setenv("FR_LS_PIPELINE", "0")
+    ref = native.train_model_shard(g, req, 0, 7)
+    assert ref["stats"]["ticks"] == st["stats"]["ticks"]
+    assert ref["stats"]["groups"] == st["stats"]["groups"]
+    assert ref["restarts"] == st["restarts"]
+
+
 def test_two_interleaved_trainers_on_one_dataset(small):
     """Only one trainer can own a dataset's resident sums; the one that loses them must keep producing
     the oracle's trajectory (it forms its sums from the tiles again)."""
