@@ -211,13 +211,15 @@ def main():
     # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
     # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
     # step, nothing else on the device) give the duration of an isolated launch; they are not part of `value`.
+    # (tools/pmc_bench.sh counts the instructions and HBM bytes of both kinds of launches of this same command.)
     iso = None
+    ISO_STEPS = 4
     if not os.environ.get("FR_LS_PIPELINE"):
         os.environ["FR_LS_PIPELINE"] = "0"
         try:
             native.profile_reset()
             native.profile_enable(True)
-            advance(min(5, args.steps))
+            advance(ISO_STEPS)
             torch.cuda.synchronize()
             native.profile_enable(False)
             iso = native.profile_stats()
@@ -269,23 +271,31 @@ def main():
         evals_per_launch = (raw / max(1, ls["launches"])) if ls["launches"] else 0.0
         avg_s = ls["avg_ms"] * 1e-3
         achieved = (b_eval * evals_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0
-        # The PMC figures of profiles/hbm_traffic.json were collected on launches of `pmc_groups` line groups
-        # (one per restart); the trainer steps the restarts as two halves (two launches per step, one in flight
-        # while the host handles the other), so a launch here carries groups_per_launch of them.
+        # PMC figures (profiles/hbm_traffic.json, collected by tools/pmc_bench.sh on THIS command): per line group of
+        # a launch, separately for the timed (pipelined, ~restarts/3 groups per launch) and the isolated launches
+        # -- the instruction count falls as training proceeds (fewer documents enter a top-k list once the model
+        # ranks the relevant ones first), so each kind of launch is priced with its own count.
         traffic = None
         valu_insts = None
+        iso_valu_insts = None
         groups_per_launch = evals_per_launch / 51.0
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(args.shape, {})
-                scale = groups_per_launch / float(tj.get("pmc_groups_per_launch", 32))
-                traffic = tj.get(dom + "_bytes_per_launch")
-                traffic = traffic * scale if traffic else None
-                valu_insts = tj.get(dom + "_valu_insts_per_launch")
-                valu_insts = valu_insts * scale if valu_insts else None
+                if dom == "linesearch_verify_kernel" and "bench_timed_valu_insts_per_group" in tj:
+                    valu_insts = tj["bench_timed_valu_insts_per_group"] * groups_per_launch
+                    iso_valu_insts = tj["bench_isolated_valu_insts_per_group"] * args.restarts_per_gpu
+                    traffic = tj["bench_timed_bytes_per_group"] * groups_per_launch
+                else:
+                    scale = groups_per_launch / float(tj.get("pmc_groups_per_launch", 32))
+                    traffic = tj.get(dom + "_bytes_per_launch")
+                    traffic = traffic * scale if traffic else None
+                    valu_insts = tj.get(dom + "_valu_insts_per_launch")
+                    valu_insts = valu_insts * scale if valu_insts else None
+                    iso_valu_insts = valu_insts / groups_per_launch * args.restarts_per_gpu if valu_insts else None
             except Exception:
-                traffic = valu_insts = None
+                traffic = valu_insts = iso_valu_insts = None
         vstats = st.get("stats", {})
         vp, vr = float(vstats.get("verify_pairs", 0)), float(vstats.get("verify_redone", 0))
         # FP64 adds the exact ordered dot products would need (what the exact kernel is bound by)
@@ -353,8 +363,8 @@ def main():
                     "avg_launch_ms": iso[dom]["avg_ms"],
                     "launches": iso[dom]["launches"],
                     "groups_per_launch": args.restarts_per_gpu,
-                    "frac": (valu_insts / groups_per_launch * args.restarts_per_gpu / (iso[dom]["avg_ms"] * 1e-3)
-                             / (1024 * 2.4e9 / 4)) if (valu_insts and iso[dom]["avg_ms"] > 0) else None,
+                    "frac": (iso_valu_insts / (iso[dom]["avg_ms"] * 1e-3) / (1024 * 2.4e9 / 4))
+                    if (iso_valu_insts and iso[dom]["avg_ms"] > 0) else None,
                     "note": "lock-step steps after the timed region (FR_LS_PIPELINE=0): one launch per step, no overlap",
                 } if (iso and dom in iso) else None),
                 "note": "bound-and-verify kernel on resident sums: three operations per document and restart for the "

@@ -748,6 +748,44 @@ def test_verify_kernel_falls_back_on_ties_and_duplicates():
             assert np.array_equal(pq[:, gi * 64 + ci], exp), (gi, ci)
 
 
+def test_redo_list_longer_than_the_first_exact_launch():
+    """The exact kernel's first launch on the redo list has a fixed grid (512 pairs, compared with the count on
+    the device); the rest of a longer list is recomputed after the results came back.  Every query here has
+    duplicated documents on top, so every (query, group) pair of 700 queries x 3 groups is on the list."""
+    rng = np.random.default_rng(5)
+    nq, per = 700, 14
+    X = rng.random((nq * per, 6)).astype(np.float32)
+    y = rng.integers(0, 3, nq * per).astype(np.float64)
+    qid = np.repeat(np.arange(1, nq + 1), per)
+    X[1::2] = X[0::2]  # pairs of identical rows: exact ties for every weight vector
+    y[0::2] = 2.0      # the duplicated rows are the relevant ones, so the ties sit among the best documents
+    y[1::2] = 2.0
+    X[0::2, 0] += 5.0
+    X[1::2, 0] += 5.0
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    feats = [0, 2, 5]
+    bases = rng.random((3, 6)) + 0.1
+    cands = [np.asarray([0.7, 0.1, 1.5]), np.asarray([0.0, 2.0]), np.asarray([-1.0, 0.25, 0.5, 3.0])]
+    for rep in range(2):  # (the second call takes the exact kernel directly: more than a quarter was redone)
+        means, pq = native.evaluate_candidates(g, "ndcg@5", feats, bases, cands, per_query=True)
+        for gi in range(3):
+            for ci in range(len(cands[gi])):
+                w = bases[gi].copy()
+                w[feats[gi]] = cands[gi][ci]
+                exp, _ = c.metric_from_scores("ndcg@5", c.score_linear(w))
+                assert np.array_equal(pq[:, gi * 64 + ci], exp), (rep, gi, ci)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@5"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 3, True, 4, 3
+    shard, st = _train_stats(g, req)
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@5", p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["verify_redone"] > 512
+
+
 def test_verify_kernel_near_ties_below_the_error_bound():
     """Scores that differ by less than the proven error bound (here ~1e-13 relative) cannot be ordered
     from the approximate sums: the pair is recomputed exactly and the result is the oracle's."""
