@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two kernels_verify.inc variants on one box (development aid)
+# A/B of two kernels_verify.inc variants on one box (development aid): put the other variant at tools/ab/kernels_verify_A.inc
 cd "$GRAFT_REPO_ROOT"
 m() { FR_LS_PIPELINE=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
