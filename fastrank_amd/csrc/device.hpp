@@ -120,6 +120,10 @@ class DeviceDataset {
     static constexpr int LINESEARCH_CONTEXTS = 4;
     bool linesearch_ndcg_submit(int ctx, int64_t depth, const double* norms, const std::vector<LineGroup>& groups, std::string* err);
     bool linesearch_ndcg_collect(int ctx, std::vector<double>* means, std::string* err);
+    // Reciprocal rank on resident sums, same contexts: *queued = false means "not applicable right now" (nothing is
+    // pending; pending resident updates were applied) and the caller evaluates the groups with linesearch_fullrank.
+    bool linesearch_rr_submit(int ctx, const std::vector<LineGroup>& groups, bool* queued, std::string* err);
+    bool linesearch_rr_collect(int ctx, std::vector<double>* means, std::string* err);
     // resident per-document sums for LineGroup::resident_slot: `slots` double-buffered arrays of np doubles
     // Returns an owner ticket (0 on failure).  A later reserve by someone else takes the buffers over: groups
     // and stores that carry the old ticket are then treated as non-resident / refused.

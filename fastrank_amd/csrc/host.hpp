@@ -851,7 +851,8 @@ class CATrainer {
             long want = pe ? atol(pe) : 3;
             want = std::min<long>(want, frdev::DeviceDataset::LINESEARCH_CONTEXTS);
             want = std::min<long>(want, (long)rs_.size());
-            parts_ = (fused_ && !shard_.allreduce && want >= 2) ? (int)want : 1;
+            const bool rr_resident = fullrank_ && ev_.measure == frdev::M_RR && resident_;
+            parts_ = ((fused_ || rr_resident) && !shard_.allreduce && want >= 2) ? (int)want : 1;
         }
         if (parts_ < 2) {
             while (n < max_ticks && (alive = tick())) n++;
@@ -862,20 +863,48 @@ class CATrainer {
         constexpr int MAXP = frdev::DeviceDataset::LINESEARCH_CONTEXTS;
         uint64_t steps[MAXP] = {};
         bool inflight[MAXP] = {};
+        bool ready[MAXP] = {};  // reciprocal rank: the set was evaluated in lock step (means_h_ already holds the result)
         auto submit = [&](int h) {
             size_t unused = 0;
             if (steps[h] >= max_ticks || !build_groups(h, groups_h_[h], &unused)) return;
             dev.set_sums_only(false);
             std::string _err;
-            if (!dev.linesearch_ndcg_submit(h, ev_.depth, ev_.norms.data(), groups_h_[h], &_err)) fail_str(_err);
+            ready[h] = false;
+            if (fused_) {
+                if (!dev.linesearch_ndcg_submit(h, ev_.depth, ev_.norms.data(), groups_h_[h], &_err)) fail_str(_err);
+            } else {
+                bool queued = false;
+                if (!dev.linesearch_rr_submit(h, groups_h_[h], &queued, &_err)) fail_str(_err);
+                if (!queued) {  // not applicable this tick (the device applied the pending resident updates): exact kernels
+                    for (frdev::LineGroup& lg : groups_h_[h]) lg.has_update = false;
+                    unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+                    dev.verify_counters(&p0, &r0);
+                    if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_h_[h], &means_h_[h], &_err))
+                        fail_str(_err);
+                    dev.verify_counters(&p1, &r1);
+                    stats_.verify_pairs += p1 - p0;
+                    stats_.verify_redone += r1 - r0;
+                    ready[h] = true;
+                }
+            }
             inflight[h] = true;
+        };
+        auto collect = [&](int h) {
+            std::string _err;
+            if (ready[h]) return;
+            if (fused_) {
+                if (!dev.linesearch_ndcg_collect(h, &means_h_[h], &_err)) fail_str(_err);
+            } else {
+                if (!dev.linesearch_rr_collect(h, &means_h_[h], &_err)) fail_str(_err);
+            }
         };
         auto drain = [&]() {  // an error is on its way out: leave no submitted line search behind
             for (int h = 0; h < parts_; h++)
-                if (inflight[h]) {
+                if (inflight[h] && !ready[h]) {
                     std::string _e;
                     std::vector<double> tmp;
-                    (void)dev.linesearch_ndcg_collect(h, &tmp, &_e);
+                    if (fused_) (void)dev.linesearch_ndcg_collect(h, &tmp, &_e);
+                    else (void)dev.linesearch_rr_collect(h, &tmp, &_e);
                     inflight[h] = false;
                 }
         };
@@ -886,11 +915,10 @@ class CATrainer {
                 for (int h = 0; h < parts_; h++) {
                     if (!inflight[h]) continue;
                     any = true;
-                    std::string _err;
                     unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
                     dev.verify_counters(&p0, &r0);
                     inflight[h] = false;
-                    if (!dev.linesearch_ndcg_collect(h, &means_h_[h], &_err)) fail_str(_err);
+                    collect(h);
                     dev.verify_counters(&p1, &r1);
                     stats_.verify_pairs += p1 - p0;
                     stats_.verify_redone += r1 - r0;

@@ -834,16 +834,17 @@ def test_trainer_variants_share_one_trajectory(small, env, monkeypatch):
     assert shard["stats"]["ticks"] > 48, "several passes over the 24 features"
 
 
-@pytest.mark.parametrize("parts", ["0", "2", "3", "4"])
-def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, parts, monkeypatch):
+@pytest.mark.parametrize("parts,measure", [("0", "ndcg@10"), ("2", "ndcg@10"), ("3", "ndcg@10"), ("4", "ndcg@10"),
+                                           ("0", "mrr"), ("3", "mrr"), ("4", "mrr")])
+def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, parts, measure, monkeypatch):
     """fr_ca_step keeps one line search of each of a few sets of restarts in flight (FR_LS_PIPELINE sets, default
-    3; 0 = plain lock step).  Whatever the split and however the ticks are chunked into calls, every restart
+    3; 0 = plain lock step; NDCG@k and reciprocal rank).  Whatever the split and however the ticks are chunked into calls, every restart
     follows the oracle's trajectory and the counters agree with lock step."""
     X, y, qid, g, c = small
     monkeypatch.setenv("FR_LS_PIPELINE", parts)
     monkeypatch.setenv("FR_RESIDENT_REFRESH", "3")  # exact refreshes on the main stream between pipelined ticks
     req = fr.TrainRequest.coordinate_ascent()
-    req.measure = "ndcg@10"
+    req.measure = measure
     p = req.params
     p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 17, True, 7, 5
     run = native.CoordinateAscentRun(g, req)
@@ -856,7 +857,7 @@ def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, 
         assert len(run.state()["restarts"]) == 7  # a consistent state between calls: nothing left in flight
     st = run.state()
     run.close()
-    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=4)
+    exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=4)
     assert err == 0
     for r in st["restarts"]:
         assert r["score"] == exp_s[r["restart_id"]], parts
