@@ -13,6 +13,27 @@ python bench.py --steps 20 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.
 # 2. rocprofv3 kernel trace + stats of the same command
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o p -- python bench.py --steps 20 --warmup 3 > "$OUT/kt.log" 2>&1
 cp "$OUT"/kt/*kernel_stats.csv "$OUT/${TAG}_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt/*/*kernel_stats.csv "$OUT/${TAG}_kernel_stats.csv"
+# the dominant kernel's launches by kind (the trainer keeps three launches in flight, bench.py appends isolated ones)
+python - "$OUT" > "$OUT/${TAG}_verify_launches.txt" <<'PY'
+import csv, glob, os, sys
+out = sys.argv[1]
+f = (glob.glob(os.path.join(out, "kt", "*kernel_trace.csv")) + glob.glob(os.path.join(out, "kt", "*", "*kernel_trace.csv")))[0]
+rows = [r for r in csv.DictReader(open(f)) if "linesearch_verify_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+gmax = max(int(r["Grid_Size"]) for r in rows)
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+iso = [r for r in rows if int(r["Grid_Size"]) == gmax]
+rest = [r for r in rows if int(r["Grid_Size"]) != gmax]
+warm, timed = rest[:9], rest[9:]
+print("rocprofv3 --kernel-trace of `python bench.py --steps 20 --warmup 3`: linesearch_verify_kernel launches by kind")
+for name, sel in (("warm-up (3 ticks x 3 sets)", warm), ("timed (20 ticks x 3 sets, overlapping)", timed), ("isolated lock-step (32 groups)", iso)):
+    if sel:
+        d = [dur(r) for r in sel]
+        print("%-42s n=%-3d avg %.4f ms  min %.4f  max %.4f" % (name, len(d), sum(d) / len(d), min(d), max(d)))
+if timed:
+    t0, t1 = int(timed[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in timed)
+    print("timed launches span %.3f ms -> %.4f ms per tick" % ((t1 - t0) / 1e6, (t1 - t0) / 1e6 / (len(timed) / 3.0)))
+PY
 # 3. secondary paths: full-ranking measures, tree ensemble, end-to-end training
 {
   for m in ndcg map mrr; do python tools/lsbench.py --reps 3 --measure $m 2>&1 | tail -6; done
