@@ -786,6 +786,34 @@ def test_redo_list_longer_than_the_first_exact_launch():
     assert st["verify_redone"] > 512
 
 
+def test_all_scores_zero_with_a_zero_error_bound():
+    """A model whose only weights sit on an all-zero column scores every document 0: the error bound computed
+    from the column maxima is 0 as well, and the approximate keys then differ only by the gain class written
+    into their lowest bits.  Those differences must not count as a proven order (the reference's tie-break puts
+    the LOWEST gain first): small queries with distinct labels are the case that would slip through."""
+    rng = np.random.default_rng(11)
+    nq = 300
+    lens = rng.integers(1, 6, nq)
+    qid = np.repeat(np.arange(1, nq + 1), lens)
+    n = len(qid)
+    X = rng.random((n, 5)).astype(np.float32)
+    X[:, 2] = 0.0
+    y = np.concatenate([rng.permutation(5)[:k] for k in lens]).astype(np.float64)  # distinct labels inside a query
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    feats = [0, 2, 2]
+    bases = np.zeros((3, 5))
+    bases[:, 2] = 1.0                      # all of the weight on the zero column
+    cands = [np.asarray([0.0]), np.asarray([1.0, -3.0, 0.0]), np.asarray([1e6, -1e6])]
+    for measure in ("ndcg@5", "ndcg@3", "ndcg@10"):
+        means, pq = native.evaluate_candidates(g, measure, feats, bases, cands, per_query=True)
+        for gi in range(3):
+            for ci in range(len(cands[gi])):
+                w = bases[gi].copy()
+                w[feats[gi]] = cands[gi][ci]
+                exp, _ = c.metric_from_scores(measure, c.score_linear(w))
+                assert np.array_equal(pq[:, gi * 64 + ci], exp), (measure, gi, ci)
+
+
 def test_verify_kernel_near_ties_below_the_error_bound():
     """Scores that differ by less than the proven error bound (here ~1e-13 relative) cannot be ordered
     from the approximate sums: the pair is recomputed exactly and the result is the oracle's."""
