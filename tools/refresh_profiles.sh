@@ -20,10 +20,10 @@ out = sys.argv[1]
 f = (glob.glob(os.path.join(out, "kt", "*kernel_trace.csv")) + glob.glob(os.path.join(out, "kt", "*", "*kernel_trace.csv")))[0]
 rows = [r for r in csv.DictReader(open(f)) if "linesearch_verify_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-gmax = max(int(r["Grid_Size"]) for r in rows)
+gmax = max(int(r["Grid_Size_X"]) for r in rows)
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-iso = [r for r in rows if int(r["Grid_Size"]) == gmax]
-rest = [r for r in rows if int(r["Grid_Size"]) != gmax]
+iso = [r for r in rows if int(r["Grid_Size_X"]) == gmax]
+rest = [r for r in rows if int(r["Grid_Size_X"]) != gmax]
 warm, timed = rest[:9], rest[9:]
 print("rocprofv3 --kernel-trace of `python bench.py --steps 20 --warmup 3`: linesearch_verify_kernel launches by kind")
 for name, sel in (("warm-up (3 ticks x 3 sets)", warm), ("timed (20 ticks x 3 sets, overlapping)", timed), ("isolated lock-step (32 groups)", iso)):
