@@ -129,7 +129,9 @@ void *fr_ca_begin(const void *train_request_json, const CDataset *dataset, uint3
 typedef int (*fr_allreduce_sum_fn)(void *ctx, double *values, size_t n);
 void *fr_ca_begin_query_shard(const void *train_request_json, const CDataset *dataset, uint64_t total_queries,
                               fr_allreduce_sum_fn allreduce, void *ctx, const void **error_out);
-/* Runs up to max_ticks ticks; NULL on success. *finished = 1 once every restart converged. */
+/* Runs up to max_ticks ticks; NULL on success. *finished = 1 once every restart converged.  Inside the call the
+ * restarts are stepped as a few sets with one line search of each in flight on the device; everything submitted has
+ * been collected and applied when the call returns, so the state is the lock-step state after *ticks_done ticks. */
 const void *fr_ca_step(void *trainer, uint64_t max_ticks, uint64_t *ticks_done, int *finished);
 /* JSON {"restarts":[...],"stats":{...},"finished":bool} (free_str). */
 const void *fr_ca_state(void *trainer);
