@@ -278,11 +278,14 @@ def main():
         traffic = None
         valu_insts = None
         iso_valu_insts = None
+        pmc_busy_frac = pmc_clock = None
         groups_per_launch = evals_per_launch / 51.0
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(args.shape, {})
+                pmc_busy_frac = tj.get("bench_timed_valu_issue_frac_of_busy_cycles")
+                pmc_clock = tj.get("bench_timed_clock_ghz")
                 if dom == "linesearch_verify_kernel" and "bench_timed_valu_insts_per_group" in tj:
                     valu_insts = tj["bench_timed_valu_insts_per_group"] * groups_per_launch
                     iso_valu_insts = tj["bench_isolated_valu_insts_per_group"] * args.restarts_per_gpu
@@ -354,6 +357,11 @@ def main():
                 "peak": 1024 * 2.4e9 / 4 / 1e9,
                 "unit": "G wave-instr/s",
                 "frac": (valu_insts * ls["launches"] / elapsed_max / (1024 * 2.4e9 / 4)) if valu_insts else None,
+                # from the PMC pass (static, profiles/hbm_traffic.json): the kernel's VALU instructions x 4 cycles over the
+                # SIMD cycles it was actually busy for (SQ_BUSY_CYCLES), and the clock those cycles imply -- the chip
+                # runs this FP64 load at ~1.9 GHz, so the 2.4 GHz peak above is not reachable by any instruction mix
+                "valu_issue_frac_of_busy_cycles": pmc_busy_frac,
+                "clock_ghz_under_load": pmc_clock,
                 "per_launch_overlapped": {
                     "avg_launch_ms": ls["avg_ms"],
                     "groups_per_launch": groups_per_launch,
