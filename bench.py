@@ -173,7 +173,7 @@ def main():
     torch.cuda.synchronize()
     upload_s = time.perf_counter() - t0
 
-    totals = {"useful_evals": 0, "raw_evals": 0}
+    totals = {"useful_evals": 0, "raw_evals": 0}  # of the jobs already finished (see advance)
     all_restarts = []
 
     def advance(nsteps):
@@ -182,22 +182,24 @@ def main():
         nonlocal run
         done = 0
         while done < nsteps:
-            before = run.state()["stats"]
             done += run.step(nsteps - done)
-            after = run.state()
-            totals["useful_evals"] += after["stats"]["useful_evals"] - before["useful_evals"]
-            totals["raw_evals"] += after["stats"]["raw_evals"] - before["raw_evals"]
             if run.finished and done < nsteps:
+                after = run.state()
+                totals["useful_evals"] += after["stats"]["useful_evals"]
+                totals["raw_evals"] += after["stats"]["raw_evals"]
                 all_restarts.extend(after["restarts"])
                 p.seed += 1
                 run.close()
                 run = native.CoordinateAscentRun(dataset, req, begin, end)
-                st = run.state()["stats"]
-                totals["useful_evals"] += st["useful_evals"]
-                totals["raw_evals"] += st["raw_evals"]
+
+    def snapshot():
+        """Evaluations so far (finished jobs + the current one); reads the trainer's state, so it is called outside
+        the timed region only."""
+        st = run.state()["stats"]
+        return {k: totals[k] + st[k] for k in totals}
 
     advance(args.warmup)
-    s0 = dict(totals)
+    s0 = snapshot()
     native.profile_reset()
     native.profile_enable(True)
     barrier()
@@ -206,7 +208,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     native.profile_enable(False)
-    s1 = dict(totals)
+    s1 = snapshot()
     prof = native.profile_stats()
     # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
     # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
