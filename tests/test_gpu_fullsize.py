@@ -13,11 +13,25 @@ from oracle import pyoracle as o
 pytestmark = pytest.mark.gpu
 
 
+_CACHE = {}
+
+
+def _shape(name):
+    if name not in _CACHE:
+        n, d, q, seed = bench.SHAPES[name]
+        X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
+        _CACHE[name] = (name, X, y, qid, fr.CDataset.from_numpy(X, y, qid))
+    return _CACHE[name]
+
+
 @pytest.fixture(scope="module", params=["10k", "30k"])
 def big(request):
-    n, d, q, seed = bench.SHAPES[request.param]
-    X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
-    return request.param, X, y, qid, fr.CDataset.from_numpy(X, y, qid)
+    return _shape(request.param)
+
+
+@pytest.fixture(scope="module")
+def big30():
+    return _shape("30k")
 
 
 def _groups(rng, d, G):
@@ -135,3 +149,94 @@ def test_verify_path_equals_exact_kernel_at_full_size(big, monkeypatch):
         assert np.array_equal(a, b)
     assert st_v["restarts"] == st_e["restarts"]
     assert st_v["stats"]["useful_evals"] == st_e["stats"]["useful_evals"]
+
+
+# ------------------------------------------------- BASELINE.json configs[4]: 500 trees x 30K shape
+
+def _forest(rng, X, ntrees, max_depth, p_leaf=0.05):
+    """fid uniform, split = a uniform quantile of that column, leaves U[0,4)."""
+    sample = X[rng.integers(0, X.shape[0], 4096)]
+
+    def grow(depth):
+        if depth >= max_depth or rng.random() < p_leaf:
+            return {"LeafNode": float(rng.uniform(0, 4))}
+        f = int(rng.integers(0, X.shape[1]))
+        return {"FeatureSplit": {"fid": f, "split": float(np.quantile(sample[:, f], rng.random())),
+                                 "lhs": grow(depth + 1), "rhs": grow(depth + 1)}}
+
+    return [grow(1) for _ in range(ntrees)]
+
+
+def _ens(trees, weights):
+    return fr.CModel.from_dict({"Ensemble": {"weights": list(weights), "models": [{"DecisionTree": t} for t in trees]}})
+
+
+def _check_slices(X, y, qid, trees, weights, got, slices):
+    for lo, hi in slices:
+        sub = o.Dataset(X[lo:hi], y[lo:hi], qid[lo:hi])
+        assert np.array_equal(sub.score_ensemble(trees, weights), got[lo:hi]), (lo, hi)
+
+
+def test_config5_500_trees_on_the_30k_shape(big30):
+    """configs[4]: the 500-tree, depth <= 8 forest over all 3.8 M documents through fr_predict_scores_dense,
+    bit-exact against the oracle (src/model.rs:64-84,104-112) on four disjoint 20 000-document slices --
+    the first block, two interior ones that straddle kernel blocks, and the ragged last block."""
+    name, X, y, qid, g = big30
+    n = len(y)
+    rng = np.random.default_rng(7)
+    trees = _forest(rng, X, 500, 8)
+    weights = [1.0] * len(trees)
+    got = native.predict_scores_dense(_ens(trees, weights), g, n)
+    assert np.isfinite(got).all()
+    slices = [(0, 20000), (1_234_567, 1_254_567), (2_500_033, 2_520_033), (n - 20000, n)]
+    _check_slices(X, y, qid, trees, weights, got, slices)
+    # signed, non-unit tree weights take the same kernel (the products w_t*leaf are formed on the host)
+    weights = rng.uniform(-1.0, 1.0, len(trees)).tolist()
+    got = native.predict_scores_dense(_ens(trees, weights), g, n)
+    _check_slices(X, y, qid, trees, weights, got, [(777_777, 787_777), (n - 10000, n)])
+
+
+def test_config5_deep_forest_fallback_on_the_30k_shape(big30):
+    """Trees outside the compact LDS encoding (depth 11, no early leaves: a level wider than 255 nodes)
+    take the L2 fallback kernel; same bits at the full size."""
+    name, X, y, qid, g = big30
+    n = len(y)
+    rng = np.random.default_rng(8)
+    trees = _forest(rng, X, 6, 11, p_leaf=0.0) + _forest(rng, X, 10, 8)
+    weights = rng.uniform(0.0, 1.0, len(trees)).tolist()
+    got = native.predict_scores_dense(_ens(trees, weights), g, n)
+    _check_slices(X, y, qid, trees, weights, got, [(0, 10000), (1_900_001, 1_910_001), (n - 10000, n)])
+
+
+# ------------------------------- BASELINE.json configs[3] on one GPU: 256 restarts as 8 restart shards
+
+def test_config4_256_restarts_as_8_shards_equal_the_unsharded_run(big30):
+    """configs[3] shards 256 restarts over 8 GPUs (32 each) and exchanges (score, weights) once.  One GPU
+    stands in for the eight: the 8 blocks of native.shard_bounds are trained one after the other with
+    fr_train_model_shard, put through gather_restarts / select_model, and must give the very restarts
+    (score, weights, per restart) and the very model of the unsharded 256-restart run
+    (src/coordinate_ascent.rs:211-251: child seeds in restart order, last maximum wins)."""
+    name, X, y, qid, g = big30
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 42, True, 256, 25
+    whole = native.train_model_shard(g, req, 0, 256)
+    assert [r["restart_id"] for r in whole["restarts"]] == list(range(256))
+    parts = []
+    for rank in range(8):
+        b, e = native.shard_bounds(256, rank, 8)
+        assert e - b == 32
+        shard = native.train_model_shard(g, req, b, e)
+        assert [r["restart_id"] for r in shard["restarts"]] == list(range(b, e))
+        parts.extend(shard["restarts"])
+    gathered = native.gather_restarts(parts, 256)
+    assert gathered == whole["restarts"]
+    a = native.select_model(gathered, False).to_dict()
+    b = native.select_model(whole["restarts"], False).to_dict()
+    assert a == b and list(a) == ["Linear"]
+    best = max(r["score"] for r in gathered)
+    last = [r for r in gathered if r["score"] == best][-1]
+    assert a["Linear"]["weights"] == last["weights"]
+    # and the plain entry point (train_model) returns that model too
+    assert g.train_model(req).to_dict() == a
