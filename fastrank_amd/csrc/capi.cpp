@@ -716,6 +716,7 @@ const void* fr_ca_state(void* trainer) {
     return json_call([&]() {
         if (!trainer) fr::fail_str("trainer pointer is null!");
         FrTrainer* h = (FrTrainer*)trainer;
+        std::lock_guard<std::mutex> lk(g_api_mu);  // fr_ca_step may be mutating the trainer on another thread
         h->t->stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
         Value o = Value::object();
         o.set("restarts", restarts_to_json(h->t->results()));
@@ -818,7 +819,13 @@ const void* fr_rank_order(const CModel* model, const CDataset* dataset, uint32_t
 
 size_t fr_dataset_num_queries(const CDataset* dataset) {
     if (!dataset) return 0;
-    return dataset->view->host_csr().nq;
+    // host_csr() validates the labels (a NaN label is an error): nothing may unwind through extern "C".
+    // SIZE_MAX = "this dataset cannot be grouped"; the compute calls report the reason in their envelope.
+    try {
+        return dataset->view->host_csr().nq;
+    } catch (...) {
+        return SIZE_MAX;
+    }
 }
 
 size_t fr_dataset_num_instances(const CDataset* dataset) {

@@ -4,6 +4,7 @@
 // (src/coordinate_ascent.rs:87-254) and feeds the device batches of candidates.
 #pragma once
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -117,6 +118,13 @@ inline uint64_t json_u64(const Value& v, const char* what) {
     if (v.kind == Value::Int && v.i >= 0) return (uint64_t)v.i;
     fail_raw(std::string("Error(\"invalid type: expected unsigned integer for ") + what + "\", line: 0, column: 0)");
 }
+// serde rejects integers that do not fit the field's type instead of truncating them
+inline uint32_t json_u32(const Value& v, const char* what) {
+    const uint64_t x = json_u64(v, what);
+    if (x > (uint64_t)UINT32_MAX)
+        fail_raw("Error(\"invalid value: integer `" + std::to_string(x) + "`, expected u32\", line: 0, column: 0)");
+    return (uint32_t)x;
+}
 inline bool json_bool(const Value& v, const char* what) {
     if (v.kind != Value::Bool) fail_raw(std::string("Error(\"invalid type: expected a boolean for ") + what + "\", line: 0, column: 0)");
     return v.b;
@@ -141,7 +149,7 @@ inline std::unique_ptr<TreeNode> tree_from_json(const Value& v) {
         node->value = json_f64(var.second, "LeafNode");
     } else if (var.first == "FeatureSplit") {
         node->leaf = false;
-        node->fid = (uint32_t)json_u64(json_field(var.second, "fid"), "fid");
+        node->fid = json_u32(json_field(var.second, "fid"), "fid");
         node->value = json_f64(json_field(var.second, "split"), "split");
         node->lhs = tree_from_json(json_field(var.second, "lhs"));
         node->rhs = tree_from_json(json_field(var.second, "rhs"));
@@ -176,7 +184,7 @@ inline Model model_from_json(const Value& v) {
         for (const auto& x : w.arr) m.weights.push_back(json_f64(x, "weights"));
     } else if (var.first == "SingleFeature") {
         m.kind = Model::SingleFeature;
-        m.fid = (uint32_t)json_u64(json_field(var.second, "fid"), "fid");
+        m.fid = json_u32(json_field(var.second, "fid"), "fid");
         m.dir = json_f64(json_field(var.second, "dir"), "dir");
     } else if (var.first == "DecisionTree") {
         m.kind = Model::DecisionTree;
@@ -457,10 +465,12 @@ inline std::shared_ptr<DatasetView> make_dense(size_t n, size_t d, const float* 
 
 // src/evaluators.rs:255-272 on gains already sorted descending; depth<0 = None
 inline double ideal_dcg_sorted_desc(const std::vector<float>& g, int64_t depth) {
-    size_t len = depth >= 0 ? (size_t)depth : g.size();
+    // zero-padding up to `depth` adds (2^0 - 1)/log2(i+2) = +0.0 terms, which leave the sum unchanged:
+    // stop at the list's end (a depth of 10^18 must not loop)
+    size_t len = depth >= 0 ? std::min<size_t>((size_t)depth, g.size()) : g.size();
     double dcg = 0.0;
     for (size_t i = 0; i < len; i++) {
-        double gain = i < g.size() ? (double)g[i] : 0.0;
+        double gain = (double)g[i];
         double term = (std::pow(2.0, gain) - 1.0) / std::log2((double)i + 2.0);
         dcg = dcg + term;
     }
@@ -478,9 +488,15 @@ inline Evaluator make_evaluator(DatasetView& view, const std::string& orig_name,
         bool ok = !num.empty();
         size_t k = (num.size() > 1 && num[0] == '+') ? 1 : 0;
         for (size_t t = k; t < num.size(); t++) ok = ok && num[t] >= '0' && num[t] <= '9';
-        if (ok && num.size() - k > 18) ok = false;
+        // usize::from_str: any digit count as long as the value fits 64 bits (leading zeros are fine)
+        uint64_t depth = 0;
+        if (ok) {
+            auto r = std::from_chars(num.data() + k, num.data() + num.size(), depth);
+            ok = r.ec == std::errc() && r.ptr == num.data() + num.size();
+        }
         if (!ok) fail_str("Couldn't parse after the @ in \"" + orig_name + "\": " + rhs);
-        ev.depth = (int64_t)std::stoull(num.substr(k));
+        // depths beyond any possible query length behave like "longer than the list": clamp for the i64 field
+        ev.depth = (int64_t)std::min<uint64_t>(depth, (uint64_t)INT64_MAX / 2);
         name = orig_name.substr(0, at);
     }
     for (auto& ch : name) ch = (char)std::tolower((unsigned char)ch);
@@ -621,8 +637,8 @@ struct CAParams {
     }
     static CAParams from_json(const Value& v) {
         CAParams p;
-        p.num_restarts = (uint32_t)json_u64(json_field(v, "num_restarts"), "num_restarts");
-        p.num_max_iterations = (uint32_t)json_u64(json_field(v, "num_max_iterations"), "num_max_iterations");
+        p.num_restarts = json_u32(json_field(v, "num_restarts"), "num_restarts");
+        p.num_max_iterations = json_u32(json_field(v, "num_max_iterations"), "num_max_iterations");
         p.step_base = json_f64(json_field(v, "step_base"), "step_base");
         p.step_scale = json_f64(json_field(v, "step_scale"), "step_scale");
         p.tolerance = json_f64(json_field(v, "tolerance"), "tolerance");
@@ -748,8 +764,21 @@ class CATrainer {
         std::vector<uint64_t> child(p_.num_restarts);
         for (uint32_t r = 0; r < p_.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
         for (uint32_t r = rbegin; r < rend; r++) rs_.emplace_back(r, child[r]);
-        fused_ = dev.linesearch_supported(ev_.measure, ev_.depth);
-        fullrank_ = !fused_ && dev.fullrank_supported(ev_.measure, ev_.depth) && !getenv("FR_FORCE_GENERIC");
+        bool can_fused = dev.linesearch_supported(ev_.measure, ev_.depth);
+        bool can_fullrank = dev.fullrank_supported(ev_.measure, ev_.depth) && !getenv("FR_FORCE_GENERIC");
+        if (shard_.allreduce) {
+            // Query shards: what a shard's device form supports depends on that shard's data (a non-finite
+            // feature, a query beyond the rank-table size, the number of gain classes), and the vector each
+            // tick hands to the exchange is laid out per path (groups*64 sums on the fused paths, one sum per
+            // candidate on the generic one).  Every rank must therefore take the same path: the one all of
+            // them support.  Counts are small integers, so the rank-ordered sum is exact.
+            double caps[3] = {can_fused ? 1.0 : 0.0, can_fullrank ? 1.0 : 0.0, 1.0};
+            shard_.allreduce(caps, 3);
+            can_fused = caps[0] == caps[2];
+            can_fullrank = caps[1] == caps[2];
+        }
+        fused_ = can_fused;
+        fullrank_ = !fused_ && can_fullrank;
         stats_.path = fused_ ? "fused_linesearch" : (fullrank_ ? "fused_fullrank" : "generic_sort");
         stats_.restarts = (uint32_t)rs_.size();
         if (rs_.empty()) return;

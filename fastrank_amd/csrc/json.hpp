@@ -98,6 +98,17 @@ class Parser {
   private:
     const char* p_;
     const char* begin_;
+    int depth_ = 0;
+    // serde_json refuses documents nested deeper than 128 ("recursion limit exceeded"); so do we,
+    // which also bounds every recursive walk over a parsed Value (tree models included).
+    static constexpr int MAX_DEPTH = 128;
+    struct Nest {
+        Parser& p;
+        explicit Nest(Parser& q) : p(q) {
+            if (++p.depth_ > MAX_DEPTH) p.fail("recursion limit exceeded");
+        }
+        ~Nest() { --p.depth_; }
+    };
 
     [[noreturn]] void fail(const std::string& msg) const {
         size_t line = 1, col = 0;
@@ -159,7 +170,19 @@ class Parser {
                 if (r.ec == std::errc() && r.ptr == tok.data() + tok.size()) return Value::uint(v);
             }
         }
-        return Value::number(strtod(tok.c_str(), nullptr));
+        // std::from_chars: locale-independent, no hex floats; out-of-range magnitudes are an error
+        // like serde_json's "number out of range" (tiny magnitudes flush to 0.0 as in serde)
+        double v = 0.0;
+        auto r = std::from_chars(tok.data(), tok.data() + tok.size(), v);
+        if (r.ec == std::errc::result_out_of_range) {
+            bool tiny = false;  // decide by the decimal exponent: underflow -> +-0.0, overflow -> error
+            size_t e = tok.find_first_of("eE");
+            if (e != std::string::npos && tok.size() > e + 1 && tok[e + 1] == '-') tiny = true;
+            if (!tiny) fail("number out of range");
+            return Value::number(tok[0] == '-' ? -0.0 : 0.0);
+        }
+        if (r.ec != std::errc() || r.ptr != tok.data() + tok.size()) fail("invalid number");
+        return Value::number(v);
     }
     static void append_utf8(std::string& out, uint32_t cp) {
         if (cp < 0x80) out += (char)cp;
@@ -221,6 +244,7 @@ class Parser {
         }
     }
     Value parse_array() {
+        Nest nest(*this);
         ++p_;
         Value v = Value::array();
         skip_ws();
@@ -235,6 +259,7 @@ class Parser {
         }
     }
     Value parse_object() {
+        Nest nest(*this);
         ++p_;
         Value v = Value::object();
         skip_ws();
@@ -276,16 +301,19 @@ inline void write_double(std::string& out, double v, bool as_f32 = false) {
         if (c != '.') digits += c;
     int len = (int)digits.size();
     int kk = exp10 + 1;  // position of the decimal point relative to the first digit
+    // ryu's pretty printer switches to exponent form outside (1e-5, 1e16) for f64 and
+    // outside (1e-6, 1e13) for f32: 1e13f -> "1e13", 1e-6f -> "0.000001"
+    const int kk_hi = as_f32 ? 13 : 16, kk_lo = as_f32 ? -6 : -5;
     if (neg) out += '-';
-    if (len <= kk && kk <= 16) {  // 1234e7 -> 12340000000.0
+    if (len <= kk && kk <= kk_hi) {  // 1234e7 -> 12340000000.0
         out += digits;
         out.append((size_t)(kk - len), '0');
         out += ".0";
-    } else if (0 < kk && kk <= 16) {  // 1234e-2 -> 12.34
+    } else if (0 < kk && kk <= kk_hi) {  // 1234e-2 -> 12.34
         out.append(digits, 0, (size_t)kk);
         out += '.';
         out.append(digits, (size_t)kk, std::string::npos);
-    } else if (-5 < kk && kk <= 0) {  // 1234e-6 -> 0.001234
+    } else if (kk_lo < kk && kk <= 0) {  // 1234e-6 -> 0.001234
         out += "0.";
         out.append((size_t)(-kk), '0');
         out += digits;

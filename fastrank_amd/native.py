@@ -29,7 +29,10 @@ def synchronize() -> None:
 
 
 def num_queries(dataset: CDataset) -> int:
-    return int(_load().fr_dataset_num_queries(dataset.pointer))
+    nq = int(_load().fr_dataset_num_queries(dataset.pointer))
+    if nq == C.c_size_t(-1).value:
+        raise ValueError("dataset cannot be grouped by query (a NaN label?): compute calls report the reason")
+    return nq
 
 
 def predict_scores_dense(model: CModel, dataset: CDataset, n_total: Optional[int] = None) -> np.ndarray:

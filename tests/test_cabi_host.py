@@ -203,3 +203,56 @@ def test_shard_bounds_cover_all_restarts():
             assert spans[0][0] == 0 and spans[-1][1] == R
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_json_nesting_limit_like_serde():
+    """serde_json stops at 128 nested containers with an error envelope; a model 200 000 levels deep must not
+    take the process down (it used to overflow the stack in the recursive parser / tree conversions)."""
+    deep = '{"DecisionTree":' + '{"FeatureSplit":{"fid":0,"split":0.5,"rhs":{"LeafNode":1.0},"lhs":' * 200000 + '{"LeafNode":0.0}' + "}}" * 200000 + "}"
+    res = clib._load().model_from_json(deep.encode("utf-8"))
+    with pytest.raises(Exception, match="recursion limit exceeded"):
+        clib._unwrap(res)
+    # 60 tree levels = 121 containers: still fine
+    t = {"LeafNode": 0.0}
+    for _ in range(60):
+        t = {"FeatureSplit": {"fid": 0, "split": 0.5, "lhs": t, "rhs": {"LeafNode": 1.0}}}
+    assert fr.CModel.from_dict({"DecisionTree": t}).to_dict() == {"DecisionTree": t}
+
+
+def test_f32_gains_print_with_ryu_f32_layout():
+    # ryu's f32 printer leaves plain notation at 1e13 / below 1e-6 (f64: 1e16 / 1e-5)
+    q = fr.CQRel.from_dict({"1": {"a": 1e13, "b": 1e-6, "c": 1e12, "d": 1e-7, "e": 2.5, "f": 0.1}})
+    raw = clib._take_str(clib._load().cqrel_query_json(q.pointer, b"1"))
+    assert json.loads(raw) == pytest.approx({"a": 1e13, "b": 1e-6, "c": 1e12, "d": 1e-7, "e": 2.5, "f": 0.1}, rel=1e-6)
+    assert '"a":1e13' in raw and '"b":0.000001' in raw and '"c":1000000000000.0' in raw and '"d":1e-7' in raw
+    assert '"e":2.5' in raw and '"f":0.1' in raw
+
+
+def test_integer_fields_are_range_checked_not_truncated(trec):
+    ds = fr.CDataset.from_numpy(trec["train_X"], trec["train_y"], trec["train_qid"])
+    req = fr.TrainRequest.coordinate_ascent()
+    req.params.num_restarts = 2 ** 32 + 1  # would silently become 1 restart under a cast
+    with pytest.raises(Exception, match="expected u32"):
+        ds.train_model(req)
+    with pytest.raises(Exception, match="expected u32"):
+        fr.CModel.from_dict({"SingleFeature": {"fid": 2 ** 40, "dir": 1.0}})
+    for text in ('{"Linear":{"weights":[0x10]}}', '{"Linear":{"weights":[1e999]}}'):
+        with pytest.raises(Exception):
+            clib._unwrap(clib._load().model_from_json(text.encode("utf-8")))
+    m = fr.CModel.from_dict({"Linear": {"weights": [0.0] * 6}})
+    with pytest.raises(Exception, match="Couldn't parse after the @"):
+        ds.evaluate(m, "ndcg@99999999999999999999999")  # does not fit usize
+    # 19 digits fit usize: parsed like the reference, the failure is then the missing GPU or nothing at all
+    try:
+        ds.evaluate(m, "ndcg@0000000000000000000005")
+    except Exception as exc:
+        assert "Couldn't parse" not in str(exc)
+
+
+def test_nan_label_does_not_unwind_through_the_c_abi():
+    X = np.zeros((3, 2), dtype=np.float32)
+    y = np.array([1.0, np.nan, 0.0])
+    qid = np.array([1, 1, 2], dtype=np.int64)
+    ds = fr.CDataset.from_numpy(X, y, qid)
+    with pytest.raises(ValueError, match="NaN label"):  # no abort: SIZE_MAX flags the bad dataset
+        native.num_queries(ds)

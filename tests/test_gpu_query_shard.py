@@ -38,7 +38,19 @@ def _split(qid, world):
     return order, bounds
 
 
-def _worker(rank, world, port, out_dir):
+def _data(long_query):
+    X, y, qid = synth_dataset(DATA["seed"], DATA["n"], DATA["d"], DATA["q"], max_len=DATA["max_len"])
+    if long_query:
+        # one 2 300-document query at the end: it lands in the last rank's block and is longer than the
+        # rank-counting kernels take (2 048), so that rank alone cannot run the fused full-ranking path
+        X2, y2, _ = synth_dataset(DATA["seed"] + 1, 2300, DATA["d"], 1, max_len=2300)
+        X = np.concatenate([X, X2])
+        y = np.concatenate([y, y2])
+        qid = np.concatenate([qid, np.full(2300, qid.max() + 1, dtype=np.int64)])
+    return X, y, qid
+
+
+def _worker(rank, world, port, out_dir, long_query=False, measures=None):
     import torch.distributed as dist
 
     import fastrank_amd as fr
@@ -48,13 +60,13 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     native.set_device(0)
-    X, y, qid = synth_dataset(DATA["seed"], DATA["n"], DATA["d"], DATA["q"], max_len=DATA["max_len"])
+    X, y, qid = _data(long_query)
     order, bounds = _split(qid, world)
     mask = np.isin(qid, order[bounds[rank]:bounds[rank + 1]])
     shard = fr.CDataset.from_numpy(np.ascontiguousarray(X[mask]), np.ascontiguousarray(y[mask]),
                                    np.ascontiguousarray(qid[mask]))
     out = {}
-    for measure in MEASURES:
+    for measure in (measures or MEASURES):
         req = fr.TrainRequest.coordinate_ascent()
         req.measure = measure
         req.params = fr.CoordinateAscentParams(**PARAMS)
@@ -95,6 +107,34 @@ def test_two_query_shards_match_the_oracle_on_the_whole_dataset(tmp_path):
                 assert r["score"] == exp_s[r["restart_id"]], measure
                 assert r["weights"] == exp_w[r["restart_id"]].tolist(), measure
             assert res["model"] == {"Linear": {"weights": exp_w[o.select_best(exp_s)].tolist()}}
+    finally:
+        o.set_mean_shards(None)
+        o.set_mean_segment(0)
+
+
+def test_shards_with_different_capabilities_agree_on_one_path(tmp_path):
+    """Only the last shard holds a query longer than the fused full-ranking kernels take.  Left to
+    itself that rank would exchange one sum per candidate and the other rank 64 per line group; the
+    ranks must settle on the path all of them support (here: the general sort evaluator) and still
+    reach the oracle's restarts."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, ["map"]), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    assert got[0] == got[1]
+    assert got[0]["map"]["path"] == "generic_sort"
+    X, y, qid = _data(True)
+    order, bounds = _split(qid, world)
+    c = o.Dataset(X, y, qid)
+    try:
+        o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+        o.set_mean_shards(bounds[:-1])
+        exp_s, exp_w, _, err = c.ca_learn("map", PARAMS, threads=2)
+        assert err == 0
+        for r in got[0]["map"]["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]]
+            assert r["weights"] == exp_w[r["restart_id"]].tolist()
     finally:
         o.set_mean_shards(None)
         o.set_mean_segment(0)
