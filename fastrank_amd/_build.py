@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libfastrank_amd.so")
 SOURCES = ["device.hip", "capi.cpp"]
 HEADERS = ["device.hpp", "host.hpp", "loader.hpp", "json.hpp", os.path.join("..", "..", "include", "fastrank.h"),
            "device_plumbing.inc", "kernels_score.inc", "kernels_tree.inc", "kernels_metric.inc",
-           "kernels_linesearch.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "device_dataset.inc"]
+           "kernels_linesearch.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "kernels_sortnet.inc", "kernels_fullverify.inc",
+           "device_dataset.inc"]
 # -ffp-contract=off is a correctness flag, not a tuning flag: the reference's dot product is an
 # unfused f64 multiply-then-add (src/dense_dataset.rs:71-74) and rank order must be bit-exact.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

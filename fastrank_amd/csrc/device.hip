@@ -16,6 +16,9 @@
 //                           kernel recomputes the pairs it cannot verify)
 //   kernels_fullrank.inc    linesearch_scores_kernel + rank_metric_kernel: AP / RR / depth-less NDCG
 //   kernels_rr.inc          rr_verify_kernel / rr_exact_kernel: reciprocal rank by bound-and-verify
+//   kernels_sortnet.inc     (generated, tools/gen_sortnet.py) compare-exchange networks over register-resident keys
+//   kernels_fullverify.inc  fullrank_verify_kernel: NDCG of any depth / AP by sorting approximate keys in registers
+//                           and verifying the gaps (the exact kernels of kernels_fullrank.inc redo what fails)
 //   device_dataset.inc      DeviceDataset: HBM layout (runs, tiles, tables) and every launcher
 #include "device.hpp"
 
@@ -41,6 +44,8 @@ namespace frdev {
 #include "kernels_verify.inc"
 #include "kernels_fullrank.inc"
 #include "kernels_rr.inc"
+#include "kernels_sortnet.inc"
+#include "kernels_fullverify.inc"
 #include "device_dataset.inc"
 
 }  // namespace frdev

@@ -124,6 +124,12 @@ class DeviceDataset {
     // pending; pending resident updates were applied) and the caller evaluates the groups with linesearch_fullrank.
     bool linesearch_rr_submit(int ctx, const std::vector<LineGroup>& groups, bool* queued, std::string* err);
     bool linesearch_rr_collect(int ctx, std::vector<double>* means, std::string* err);
+    // The same protocol for every full-ranking measure: reciprocal rank as above; NDCG of any depth and AP by sorting
+    // approximate keys in registers and verifying the gaps between neighbours of different gain class
+    // (kernels_fullverify.inc; works from resident sums or, for stateless callers, from the feature tiles).
+    bool linesearch_fullrank_submit(int ctx, int measure, int64_t depth, const double* norms,
+                                    const std::vector<LineGroup>& groups, bool* queued, std::string* err);
+    bool linesearch_fullrank_collect(int ctx, std::vector<double>* means, std::string* err);
     // resident per-document sums for LineGroup::resident_slot: `slots` double-buffered arrays of np doubles
     // Returns an owner ticket (0 on failure).  A later reserve by someone else takes the buffers over: groups
     // and stores that carry the old ticket are then treated as non-resident / refused.

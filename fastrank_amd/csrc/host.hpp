@@ -809,7 +809,7 @@ class CATrainer {
         // R ~ sum_j x_j * best_w_j for every document, so a tick reads 24 bytes per document and restart instead
         // of the whole feature row.  FR_LS_RESIDENT=0 turns it off (every tick then forms the sums from the tiles).
         const char* res_env = getenv("FR_LS_RESIDENT");
-        if ((fused_ || (fullrank_ && ev_.measure == frdev::M_RR)) && !(res_env && res_env[0] == '0')) {
+        if ((fused_ || fullrank_) && !(res_env && res_env[0] == '0')) {
             std::string _err;
             res_owner_ = dev.resident_reserve(R, &_err);
             if (res_owner_ != 0) {
@@ -880,8 +880,8 @@ class CATrainer {
             long want = pe ? atol(pe) : 3;
             want = std::min<long>(want, frdev::DeviceDataset::LINESEARCH_CONTEXTS);
             want = std::min<long>(want, (long)rs_.size());
-            const bool rr_resident = fullrank_ && ev_.measure == frdev::M_RR && resident_;
-            parts_ = ((fused_ || rr_resident) && !shard_.allreduce && want >= 2) ? (int)want : 1;
+            const bool fr_resident = fullrank_ && resident_;  // (MRR, NDCG of any depth, MAP: bound-and-verify on resident sums)
+            parts_ = ((fused_ || fr_resident) && !shard_.allreduce && want >= 2) ? (int)want : 1;
         }
         if (parts_ < 2) {
             while (n < max_ticks && (alive = tick())) n++;
@@ -903,7 +903,8 @@ class CATrainer {
                 if (!dev.linesearch_ndcg_submit(h, ev_.depth, ev_.norms.data(), groups_h_[h], &_err)) fail_str(_err);
             } else {
                 bool queued = false;
-                if (!dev.linesearch_rr_submit(h, groups_h_[h], &queued, &_err)) fail_str(_err);
+                if (!dev.linesearch_fullrank_submit(h, ev_.measure, ev_.depth, ev_.norms.data(), groups_h_[h], &queued, &_err))
+                    fail_str(_err);
                 if (!queued) {  // not applicable this tick (the device applied the pending resident updates): exact kernels
                     for (frdev::LineGroup& lg : groups_h_[h]) lg.has_update = false;
                     unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
@@ -924,7 +925,7 @@ class CATrainer {
             if (fused_) {
                 if (!dev.linesearch_ndcg_collect(h, &means_h_[h], &_err)) fail_str(_err);
             } else {
-                if (!dev.linesearch_rr_collect(h, &means_h_[h], &_err)) fail_str(_err);
+                if (!dev.linesearch_fullrank_collect(h, &means_h_[h], &_err)) fail_str(_err);
             }
         };
         auto drain = [&]() {  // an error is on its way out: leave no submitted line search behind
@@ -933,7 +934,7 @@ class CATrainer {
                     std::string _e;
                     std::vector<double> tmp;
                     if (fused_) (void)dev.linesearch_ndcg_collect(h, &tmp, &_e);
-                    else (void)dev.linesearch_rr_collect(h, &tmp, &_e);
+                    else (void)dev.linesearch_fullrank_collect(h, &tmp, &_e);
                     inflight[h] = false;
                 }
         };

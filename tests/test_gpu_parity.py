@@ -967,6 +967,70 @@ def test_mrr_training_by_bound_and_verify(small, ties):
     assert st["useful_evals"] == int(exp_e.sum())
 
 
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("measure", ["ndcg", "map", "ndcg@50"])
+def test_fullrank_training_by_sort_and_verify(small, measure, ties):
+    """The reference's default measure (NDCG without a depth), MAP and NDCG beyond depth 20 train through
+    fullrank_verify_kernel on resident sums: approximate keys sorted in registers, gaps between neighbours of different
+    gain class verified; ties and duplicated documents fail the verification and go to the exact kernels' work-list
+    mode.  Either way the trajectory is the oracle's (src/evaluators.rs:255-272, 350-380, 422-447)."""
+    X, y, qid, g, c = small
+    if ties:
+        X = np.round(X * 2).astype(np.float32)
+        X[1::2] = X[0::2][: len(X[1::2])]
+        g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = measure
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 19, True, 3, 5
+    shard = native.train_model_shard(g, req, 0, 3)
+    st = shard["stats"]
+    assert st["path"] == "fused_fullrank"
+    if _verify_path_on() and not os.environ.get("FR_FV_OFF"):
+        assert st["verify_pairs"] > 0
+        if ties:
+            assert st["verify_redone"] > 0
+    exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["useful_evals"] == int(exp_e.sum())
+
+
+@pytest.mark.parametrize("measure", ["ndcg", "map", "ndcg@100"])
+def test_fullrank_verify_every_size_class(measure):
+    """Queries of 1 .. 2048 documents cover every instantiation of the sort kernel (16/32/64 keys in one lane; 2, 4,
+    8, 16, 32 lanes per candidate with cross-lane merge rounds), with negative gains, a query without relevant
+    documents, and near-duplicate columns: per-query values against the oracle, stateless (sums from the tiles)."""
+    lens = np.array([1, 2, 7, 15, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 200, 256, 300, 511, 513, 1000, 1025, 2048, 40])
+    rng = np.random.default_rng(71)
+    qid = np.repeat(np.arange(1, len(lens) + 1, dtype=np.int64), lens)
+    n, d = len(qid), 12
+    X = rng.normal(0, 1, (n, d)).astype(np.float32)
+    X[:, 3] = np.floor(rng.exponential(2.0, n)).astype(np.float32)  # integer column: exact ties when it carries the weight
+    X[:, 7] = np.where(rng.random(n) < 0.7, 0.0, rng.random(n)).astype(np.float32)
+    y = rng.choice([0.0, 0.0, 1.0, 2.0, 3.0, 4.0], n)
+    y[qid == 5] = 0.0
+    y[(qid == 12) & (y == 0)] = -1.0
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    feats, bases, cands = _ca_groups(rng, d, 4, iters=25)
+    feats[0], feats[1] = 3, 7
+    bases[2][:] = 0.0
+    bases[2][3] = 1.0  # group 2: all weight on the integer column -> ties inside and across classes
+    feats[2] = 5
+    for gi in range(4):
+        cands[gi] = o.ca_candidates(bases[gi][feats[gi]], 0.05, 2.0, 25)
+    means, pq = native.evaluate_candidates(g, measure, feats, bases, cands, per_query=True)
+    norms = c.default_norms(measure)
+    for gi in range(4):
+        for ci in range(len(cands[gi])):
+            w = bases[gi].copy()
+            w[feats[gi]] = cands[gi][ci]
+            exp, err = c.metric_from_scores(measure, c.score_linear(w), norms)
+            assert err == 0
+            assert np.array_equal(pq[:, gi * 64 + ci], exp), (measure, gi, ci, np.nonzero(pq[:, gi * 64 + ci] != exp)[0])
+
+
 @pytest.mark.parametrize("measure", ["ndcg@3", "ndcg@20", "ndcg@1"])
 def test_resident_training_other_depths(small, measure):
     X, y, qid, g, c = small

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=8)
     ap.add_argument("--measure", default="ndcg@10")
     ap.add_argument("--max-ticks", type=int, default=100000)
+    ap.add_argument("--profile", action="store_true", help="HIP-event time per kernel (use with FR_LS_PIPELINE=0: overlapping launches inflate it)")
     args = ap.parse_args()
     n, d, q, seed = bench.SHAPES[args.shape]
     X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
@@ -34,15 +35,22 @@ def main():
     t0 = time.perf_counter()
     run = native.CoordinateAscentRun(ds, req)
     t_init = time.perf_counter() - t0
+    if args.profile:
+        native.profile_reset()
+        native.profile_enable(True)
     t0 = time.perf_counter()
     ticks = 0
     while not run.finished and ticks < args.max_ticks:
-        ticks += run.step(136)
+        ticks += run.step(min(136, args.max_ticks - ticks))
         st = run.state()
         print("  ticks=%d best=%.6f useful=%d raw=%d elapsed=%.1fs" % (
             ticks, max(r["score"] for r in st["restarts"]), st["stats"]["useful_evals"], st["stats"]["raw_evals"],
             time.perf_counter() - t0), flush=True)
     wall = time.perf_counter() - t0
+    if args.profile:
+        native.profile_enable(False)
+        for name, v in sorted(native.profile_stats().items()):
+            print("   %-30s launches=%d avg=%.3f ms total=%.1f ms" % (name, v["launches"], v["avg_ms"], v["total_ms"]))
     st = run.state()
     model = native.select_model(st["restarts"], False)
     mean = float(np.mean(native.evaluate_dense(model, ds, args.measure)[1]))
