@@ -40,7 +40,8 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp", "-lz"]
+    extra = os.environ.get("FR_BUILD_FLAGS", "").split()  # kernel-tuning experiments (-DFV_WAVES_64=2 ...)
+    cmd = [hipcc_path()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp", "-lz"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

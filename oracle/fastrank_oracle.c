@@ -787,3 +787,21 @@ size_t oracle_ca_candidates(double orig, double step_base, double step_scale, ui
     }
     return n;
 }
+
+
+/* Test support for kernels_fullverify.inc (AP terms): counts the pairs 1 <= a <= b <= maxb for which
+ * q1 = fma(fma(-q0, b, a), y, q0), y = 1/b, q0 = a*y differs from the IEEE quotient a / b that
+ * src/evaluators.rs:443 computes.  The device forms recall / rank this way from a table of reciprocals. */
+long oracle_check_div_identity(int maxb) {
+    long bad = 0;
+    for (int b = 1; b <= maxb; b++) {
+        volatile double y = 1.0 / (double)b;
+        for (int a = 1; a <= b; a++) {
+            volatile double q0 = (double)a * y;
+            double r = fma(-q0, (double)b, (double)a);
+            double q1 = fma(r, y, q0);
+            if (q1 != (double)a / (double)b) bad++;
+        }
+    }
+    return bad;
+}

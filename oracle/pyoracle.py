@@ -80,6 +80,8 @@ def lib():
     L.oracle_get_mean_segment.restype = sz
     L.oracle_mean.restype = dbl
     L.oracle_mean.argtypes = [vp, sz]
+    L.oracle_check_div_identity.restype = C.c_long
+    L.oracle_check_div_identity.argtypes = [C.c_int]
     L.oracle_rand64_stream.argtypes = [u64, sz, vp]
     L.oracle_shuffle_with_seed.argtypes = [u64, vp, sz]
     _lib = L
@@ -310,3 +312,8 @@ def shuffle_with_seed(seed, n):
     v = np.arange(n, dtype=np.uint32)
     lib().oracle_shuffle_with_seed(seed, _p(v), n)
     return v
+
+
+def check_div_identity(maxb: int) -> int:
+    """Pairs 1 <= a <= b <= maxb where the 2-FMA quotient of kernels_fullverify.inc differs from a / b."""
+    return int(lib().oracle_check_div_identity(int(maxb)))

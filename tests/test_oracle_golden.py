@@ -160,3 +160,10 @@ def test_ca_improves_and_is_thread_invariant(trec):
     # restart shard returns the same restarts
     s_sh, w_sh, _, _ = ds.ca_learn("ndcg@5", params, threads=2, restart_range=(2, 4))
     assert (s_sh[2:] == s1[2:]).all() and (w_sh[2:] == w1[2:]).all()
+
+
+def test_two_fma_quotient_equals_ieee_division_for_every_rank_pair():
+    """fullrank_verify_kernel forms the AP term recall / rank as q0 = recall * y, q1 = fma(fma(-q0, rank, recall), y, q0)
+    with y = 1 / rank: identical to the IEEE quotient the reference computes (src/evaluators.rs:443) for every pair
+    the kernel can meet (ranks up to 2048; checked up to 4096, 8.4 million pairs)."""
+    assert o.check_div_identity(4096) == 0
