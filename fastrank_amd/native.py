@@ -245,7 +245,9 @@ def shard_bounds(num_restarts: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_restarts(mine: List[Dict], num_restarts: int, group=None) -> List[Dict]:
     """The job's single exchange: one all_gather of fixed-size (valid, restart_id, score, weights)
     records over RCCL/xGMI (backend "nccl") or gloo (CPU test rigs).  Returns every rank's
-    restarts in restart order, identically on every rank."""
+    restarts in restart order, identically on every rank.  Ranks may hold different numbers of
+    restarts (block partition with a remainder, or work stealing): the record count is the maximum
+    over ranks, agreed in the same small all-reduce that agrees the weight dimension."""
     import torch
     import torch.distributed as dist
 
@@ -254,10 +256,9 @@ def gather_restarts(mine: List[Dict], num_restarts: int, group=None) -> List[Dic
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    dim_t = torch.tensor([max((len(r["weights"]) for r in mine), default=0)], dtype=torch.int64, device=dev)
-    dist.all_reduce(dim_t, op=dist.ReduceOp.MAX, group=group)
-    dim = int(dim_t.item())
-    per_rank = (num_restarts + world - 1) // world
+    shape_t = torch.tensor([max((len(r["weights"]) for r in mine), default=0), len(mine)], dtype=torch.int64, device=dev)
+    dist.all_reduce(shape_t, op=dist.ReduceOp.MAX, group=group)
+    dim, per_rank = int(shape_t[0].item()), max(1, int(shape_t[1].item()))
     buf = torch.zeros((per_rank, 3 + dim), dtype=torch.float64)
     for k, r in enumerate(mine):
         buf[k, 0] = 1.0
@@ -273,7 +274,55 @@ def gather_restarts(mine: List[Dict], num_restarts: int, group=None) -> List[Dic
             if row[0] == 1.0:
                 restarts.append({"restart_id": int(row[1]), "score": row[2], "weights": row[3:]})
     restarts.sort(key=lambda r: r["restart_id"])
+    if len(restarts) != num_restarts or any(r["restart_id"] != i for i, r in enumerate(restarts)):
+        raise RuntimeError("gather_restarts: expected restarts 0..{} exactly once, got {}".format(
+            num_restarts - 1, [r["restart_id"] for r in restarts]))
     return restarts
+
+
+_steal_jobs = 0
+
+
+def steal_blocks(num_restarts: int, block: int, group=None, store=None):
+    """Work stealing over restart blocks (restarts converge after different
+    numbers of ticks, so a static partition leaves GPUs idle at the end): yields [begin, end)
+    blocks of `block` consecutive restart ids pulled from ONE shared counter -- an atomic add on
+    the process group's rendezvous store (TCP), no data-path collective.  Which rank trains which
+    block does not matter: a restart's trajectory depends only on its child seed
+    (src/coordinate_ascent.rs:211-225)."""
+    import torch.distributed as dist
+
+    global _steal_jobs
+    key = "fastrank_amd/steal/{}".format(_steal_jobs)  # every rank calls in the same order: same key
+    _steal_jobs += 1
+    if not dist.is_available() or not dist.is_initialized():
+        for b in range(0, num_restarts, block):
+            yield b, min(num_restarts, b + block)
+        return
+    if store is None:
+        store = dist.distributed_c10d._get_default_store()
+    while True:
+        k = int(store.add(key, 1)) - 1
+        if k * block >= num_restarts:
+            return
+        yield k * block, min(num_restarts, (k + 1) * block)
+
+
+def train_model_work_stealing(dataset: CDataset, train_req, block: int = 8, group=None, store=None, stats: Optional[Dict] = None) -> CModel:
+    """Like train_model_distributed, but the ranks pull restart blocks from a shared counter instead of
+    taking one static block each.  Same model on every rank, identical to the unsharded run."""
+    R = int(train_req.params.num_restarts)
+    mine, blocks = [], []
+    for begin, end in steal_blocks(R, block, group, store):
+        shard = train_model_shard(dataset, train_req, begin, end)
+        mine.extend(shard["restarts"])
+        blocks.append((begin, end))
+    if stats is not None:
+        stats["blocks"] = blocks
+    restarts = gather_restarts(mine, R, group)
+    model = select_model(restarts, bool(train_req.params.output_ensemble))
+    model.params = train_req
+    return model
 
 
 def train_model_distributed(dataset: CDataset, train_req, group=None) -> CModel:

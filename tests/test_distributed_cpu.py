@@ -118,3 +118,50 @@ def test_oracle_sharded_mean_shape():
     finally:
         o.set_mean_shards(None)
         o.set_mean_segment(0)
+
+
+def _steal_worker(rank, world, port, out_dir, R, block):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = np.load(os.path.join(GOLDEN, "trec_news_2018.npz"))
+    ds = o.Dataset(d["train_X"], d["train_y"], d["train_qid"])
+    params = dict(PARAMS, num_restarts=R)
+    mine, blocks = [], []
+    for begin, end in native.steal_blocks(R, block):
+        if rank == 0 and not blocks:
+            import time
+            time.sleep(0.3)  # a slow rank: the others must take its share
+        scores, weights, _, err = ds.ca_learn("ndcg@5", params, threads=1, restart_range=(begin, end))
+        assert err == 0
+        mine += [{"restart_id": r, "score": float(scores[r]), "weights": weights[r].tolist()} for r in range(begin, end)]
+        blocks.append([begin, end])
+    allr = native.gather_restarts(mine, R)
+    model = native.select_model(allr, False)
+    # a second job on the same process group draws from a fresh counter
+    again = [list(b) for b in native.steal_blocks(3, 2)]
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:
+        json.dump({"model": model.to_dict(), "blocks": blocks, "again": again,
+                   "restarts": [[r["restart_id"], r["score"]] for r in allr]}, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_work_stealing_blocks_cover_every_restart_once_and_select_the_same_model(tmp_path, world):
+    R, block = 7, 2  # ragged last block
+    mp.spawn(_steal_worker, args=(world, _free_port(), str(tmp_path), R, block), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    taken = sorted(tuple(b) for g in got for b in g["blocks"])
+    assert taken == [(0, 2), (2, 4), (4, 6), (6, 7)], "each block pulled by exactly one rank"
+    assert sorted(tuple(b) for g in got for b in g["again"]) == [(0, 2), (2, 3)]
+    assert all(g["model"] == got[0]["model"] and g["restarts"] == got[0]["restarts"] for g in got[1:])
+    d = np.load(os.path.join(GOLDEN, "trec_news_2018.npz"))
+    ds = o.Dataset(d["train_X"], d["train_y"], d["train_qid"])
+    scores, weights, _, _ = ds.ca_learn("ndcg@5", dict(PARAMS, num_restarts=R), threads=2)
+    assert got[0]["model"] == {"Linear": {"weights": weights[o.select_best(scores)].tolist()}}
+    assert [s for _, s in got[0]["restarts"]] == scores.tolist()
+
+
+def test_steal_blocks_without_process_group_is_the_plain_block_list():
+    assert list(native.steal_blocks(10, 4)) == [(0, 4), (4, 8), (8, 10)]
