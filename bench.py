@@ -9,12 +9,20 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     reference's sequential accept/early-break logic;
   * W untimed steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize();
     time = max over ranks; value = useful evaluations of all ranks / time;
-  * weak scaling: 32 restarts per GPU (BASELINE.json configs[2] at N=1, configs[3] at N=8),
-    dataset replicated, restarts block-partitioned, one all-gather of (restart, score, weights)
-    at the end of training (not part of a step).
+  * weak scaling (default): 32 restarts per GPU (BASELINE.json configs[2] at N=1, configs[3] at N=8),
+    dataset replicated, restarts block-partitioned, no data-path collective;
+    strong scaling (--restarts-total R): one fixed job of R restarts split over the ranks.
+After the timed steps (never part of `value`):
+  * a few lock-step steps (one launch per step, nothing else on the device): the ISOLATED launch the roofline
+    object is computed from;
+  * one whole job trained to convergence INCLUDING its single all-gather and the model selection (`e2e`:
+    time-to-model, per-rank ticks / busy time / idle share -- the load imbalance restart sharding has;
+    --steal-block B lets the ranks pull blocks of B restarts from a shared counter instead);
+  * the CPU baseline (oracle/, rank 0, N=1 only).
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,11 +42,21 @@ SHAPES = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TADDS = 39.3    # 78.6 TFLOP/s FP64 vector (FMA = 2 flop) -> 39.3 T adds/s
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9
+# sources whose SHA-1 the PMC figures of profiles/hbm_traffic.json are tied to (tools/pmc_bench.sh records them)
+PMC_SOURCES = ("kernels_verify.inc", "kernels_linesearch.inc", "device_dataset.inc", "host.hpp")
+DATA_KINDS = ("mslr", "ties", "hard")
 
 
-def gen_mslr_shaped(seed, n, d, q):
+def gen_mslr_shaped(seed, n, d, q, kind="mslr"):
     """Synthetic MSLR-like matrix: lognormal query lengths, 5-grade labels,
-    columns cycling uniform / small-integer (ties) / heavy-tail / sparse, label signal in 16."""
+    columns cycling uniform / small-integer (ties) / heavy-tail / sparse, label signal in 16.
+    kind="hard": the label signal is 0.03*label instead of 0.3*label (rankings stay noisy, many
+    documents keep entering the top-k lists).  kind="ties": every column floor()-quantised (small
+    integers, like most MSLR columns) and 20 % of each query's documents are exact duplicates
+    (features and label) of another document of the query -- score ties the reference resolves
+    by its gain/id tie-break, i.e. pairs the bound-and-verify kernels must hand to the exact ones."""
     rng = np.random.default_rng(seed)
     lens = np.clip(rng.lognormal(np.log(100.0), 0.6, q), 1, 1300)
     lens = np.maximum(1, np.floor(lens * (n / lens.sum()))).astype(np.int64)
@@ -59,6 +77,7 @@ def gen_mslr_shaped(seed, n, d, q):
     y = rng.choice(5, size=n, p=[0.515, 0.324, 0.134, 0.019, 0.008]).astype(np.float64)
     XT = np.empty((d, n), dtype=np.float32)
     signal = set(range(0, 128, 8)) if d >= 128 else set(range(0, d, 8))
+    coef = 0.03 if kind == "hard" else 0.3
     for j in range(d):
         m = j % 4
         if m == 0:
@@ -70,11 +89,51 @@ def gen_mslr_shaped(seed, n, d, q):
         else:
             col = np.where(rng.random(n) < 0.7, 0.0, rng.random(n))
         if j in signal:
-            col = col + 0.3 * y
+            col = col + coef * y
+        if kind == "ties":
+            col = np.floor(col * 4.0)
         XT[j] = col.astype(np.float32)
     X = np.ascontiguousarray(XT.T)
     del XT
+    if kind == "ties":
+        starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+        dup = np.nonzero(rng.random(n) < 0.2)[0]
+        qi = np.searchsorted(starts, dup, side="right") - 1
+        src = starts[qi] + np.floor(rng.random(len(dup)) * lens[qi]).astype(np.int64)
+        Xs, ys = X[src].copy(), y[src].copy()
+        X[dup], y[dup] = Xs, ys
     return X, y, qid
+
+
+def source_sha1():
+    """SHA-1 of the kernel / trainer sources the PMC constants depend on."""
+    out = {}
+    for name in PMC_SOURCES:
+        path = os.path.join(ROOT, "fastrank_amd", "csrc", name)
+        out[name] = hashlib.sha1(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+    return out
+
+
+def load_pmc(shape, usable):
+    """Static rocprofv3 --pmc figures (profiles/hbm_traffic.json, captured by tools/pmc_bench.sh on THIS command).
+    They are NOT measured in this run: the object says where they come from, which sources they were captured on,
+    and `stale` when those sources differ from the ones built here (or when the capture carries no hashes)."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    meta = {"source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes over `python bench.py --steps 20 --warmup 3`, "
+                      "tools/pmc_bench.sh); static, not measured in this run", "current_sha1": source_sha1()}
+    if not usable:
+        meta.update({"stale": None, "note": "PMC figures exist only for the headline workload (mslr data, ndcg@10): none applied"})
+        return {}, meta
+    try:
+        tj = json.load(open(tpath)).get(shape, {})
+    except Exception as exc:
+        meta.update({"stale": True, "note": "unreadable: {}".format(exc)})
+        return {}, meta
+    cap = tj.get("captured") or {}
+    meta["captured_sha1"] = cap.get("sha1")
+    meta["captured_round"] = cap.get("round")
+    meta["stale"] = (cap.get("sha1") != meta["current_sha1"])
+    return tj, meta
 
 
 def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
@@ -118,7 +177,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shape", default=os.environ.get("FR_BENCH_SHAPE", "30k"), choices=sorted(SHAPES))
+    ap.add_argument("--data", default=os.environ.get("FR_BENCH_DATA", "mslr"), choices=DATA_KINDS,
+                    help="mslr = headline; ties / hard = side measurements (see gen_mslr_shaped)")
     ap.add_argument("--restarts-per-gpu", type=int, default=32)
+    ap.add_argument("--restarts-total", type=int, default=0,
+                    help="strong scaling: one fixed job of this many restarts split over the ranks (0 = weak scaling)")
+    ap.add_argument("--steal-block", type=int, default=0,
+                    help="e2e leg: ranks pull blocks of this many restarts from a shared counter (0 = static block partition)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the train-to-convergence leg")
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -151,30 +217,46 @@ def main():
     native.set_device(dev_ordinal)
     n, d, q, seed = SHAPES[args.shape]
     t0 = time.perf_counter()
-    X, y, qid = gen_mslr_shaped(seed, n, d, q)
+    X, y, qid = gen_mslr_shaped(seed, n, d, q, args.data)
     gen_s = time.perf_counter() - t0
     dataset = fr.CDataset.from_numpy(X, y, qid)
 
-    R = args.restarts_per_gpu * world
+    strong = args.restarts_total > 0
+    R = args.restarts_total if strong else args.restarts_per_gpu * world
     req = fr.TrainRequest.coordinate_ascent()
     req.measure = args.measure
     p = req.params
     p.num_restarts, p.num_max_iterations, p.step_base, p.step_scale = R, 25, 0.05, 2.0
     p.tolerance, p.normalize, p.init_random, p.seed, p.quiet = 0.001, True, True, 42, True
     begin, end = native.shard_bounds(R, rank, world)
+    my_restarts = end - begin
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def allgather_rows(row):
+        """[world][len(row)] float64 table of one small row per rank (reporting only)."""
+        t = torch.tensor(row, dtype=torch.float64, device=coll_dev)
+        if world == 1:
+            return [t.cpu().tolist()]
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return [x.cpu().tolist() for x in parts]
+
     t0 = time.perf_counter()
     run = native.CoordinateAscentRun(dataset, req, begin, end)  # uploads + initial evaluate_mean per restart
     torch.cuda.synchronize()
     upload_s = time.perf_counter() - t0
 
-    totals = {"useful_evals": 0, "raw_evals": 0}  # of the jobs already finished (see advance)
-    all_restarts = []
+    totals = {"useful_evals": 0, "raw_evals": 0, "verify_pairs": 0, "verify_redone": 0, "exact_ticks": 0, "ticks": 0,
+              "line_searches": 0}
+    jobs = {"finished": 0}
+
+    def add_stats(stats):
+        for k in totals:
+            totals[k] += int(stats.get(k, 0) or 0)
 
     def advance(nsteps):
         """Runs exactly nsteps ticks; when every restart of the current job has converged a new job
@@ -184,19 +266,17 @@ def main():
         while done < nsteps:
             done += run.step(nsteps - done)
             if run.finished and done < nsteps:
-                after = run.state()
-                totals["useful_evals"] += after["stats"]["useful_evals"]
-                totals["raw_evals"] += after["stats"]["raw_evals"]
-                all_restarts.extend(after["restarts"])
+                add_stats(run.state()["stats"])
+                jobs["finished"] += 1
                 p.seed += 1
                 run.close()
                 run = native.CoordinateAscentRun(dataset, req, begin, end)
 
     def snapshot():
-        """Evaluations so far (finished jobs + the current one); reads the trainer's state, so it is called outside
+        """Counters so far (finished jobs + the current one); reads the trainer's state, so it is called outside
         the timed region only."""
         st = run.state()["stats"]
-        return {k: totals[k] + st[k] for k in totals}
+        return {k: totals[k] + int(st.get(k, 0) or 0) for k in totals}
 
     advance(args.warmup)
     s0 = snapshot()
@@ -212,19 +292,23 @@ def main():
     prof = native.profile_stats()
     # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
     # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
-    # step, nothing else on the device) give the duration of an isolated launch; they are not part of `value`.
-    # (tools/pmc_bench.sh counts the instructions and HBM bytes of both kinds of launches of this same command.)
+    # step, nothing else on the device) give the duration of an ISOLATED launch: the roofline object below is computed
+    # from it.  They are not part of `value`.  (tools/pmc_bench.sh counts the instructions and HBM bytes of both kinds
+    # of launches of this same command.)
     iso = None
+    iso_evals = 0
     ISO_STEPS = 4
     if not os.environ.get("FR_LS_PIPELINE"):
         os.environ["FR_LS_PIPELINE"] = "0"
         try:
+            i0 = snapshot()
             native.profile_reset()
             native.profile_enable(True)
             advance(ISO_STEPS)
             torch.cuda.synchronize()
             native.profile_enable(False)
             iso = native.profile_stats()
+            iso_evals = snapshot()["raw_evals"] - i0["raw_evals"]
         finally:
             del os.environ["FR_LS_PIPELINE"]
 
@@ -239,75 +323,172 @@ def main():
         elapsed_max, useful_all, raw_all = float(tmax[0]), float(tsum[1]), float(tsum[2])
     else:
         elapsed_max, useful_all, raw_all = elapsed, float(useful), float(raw)
+    best_so_far = max(r["score"] for r in run.state()["restarts"]) if my_restarts else float("nan")
+    run.close()
 
-    # the job's single exchange: all-gather (restart, score, weights) + deterministic selection
-    t0 = time.perf_counter()
-    st = run.state()
-    mine = st["restarts"]
-    if world > 1:
-        dim = d
-        buf = torch.zeros((args.restarts_per_gpu + 1, 3 + dim), dtype=torch.float64, device=coll_dev)
-        for k, r in enumerate(mine):
-            buf[k, 0], buf[k, 1], buf[k, 2] = 1.0, float(r["restart_id"]), r["score"]
-            buf[k, 3:3 + len(r["weights"])] = torch.tensor(r["weights"], dtype=torch.float64)
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf)
+    # ---- second leg: one whole job to convergence, INCLUDING the job's single exchange and the selection ----------
+    e2e = None
+    if not args.no_e2e:
+        p.seed = 42
+        barrier()
+        t0 = time.perf_counter()
+        mine, blocks, ticks, e_stats = [], [], 0, dict.fromkeys(totals, 0)
+        chunks = native.steal_blocks(R, args.steal_block) if args.steal_block > 0 else ([(begin, end)] if my_restarts else [])
+        for b, e in chunks:
+            job = native.CoordinateAscentRun(dataset, req, b, e)
+            while not job.finished:
+                ticks += job.step(1 << 20)
+            st = job.state()
+            job.close()
+            mine.extend(st["restarts"])
+            blocks.append([b, e])
+            for k in e_stats:
+                e_stats[k] += int(st["stats"].get(k, 0) or 0)
         torch.cuda.synchronize()
-        allr = [{"restart_id": int(row[1]), "score": row[2], "weights": row[3:]}
-                for t in gathered for row in t.cpu().tolist() if row[0] == 1.0]
+        busy_s = time.perf_counter() - t0
+        allr = native.gather_restarts(mine, R) if world > 1 else sorted(mine, key=lambda r: r["restart_id"])
+        model = native.select_model(allr, False)
+        barrier()
+        e2e_s = time.perf_counter() - t0
+        rows = allgather_rows([float(ticks), busy_s, float(e_stats["useful_evals"]), float(e_stats["raw_evals"]),
+                               float(len(mine)), float(e_stats["verify_pairs"]), float(e_stats["verify_redone"]),
+                               float(e_stats["exact_ticks"]), e2e_s, float(e_stats["line_searches"])])
+        wall = max(r[8] for r in rows)
+        busy = [r[1] for r in rows]
+        best = max(allr, key=lambda r: r["score"])
+        e2e = {
+            "what": "one job of {} restarts trained to convergence, all-gather of (restart, score, weights) and last-max "
+                    "selection included (time-to-model); {}".format(
+                        R, "work stealing in blocks of {}".format(args.steal_block) if args.steal_block > 0 else "static block partition"),
+            "wall_s": wall,
+            "useful_evals": sum(r[2] for r in rows),
+            "e2e_evals_per_s": sum(r[2] for r in rows) / wall,
+            "per_rank_ticks": [int(r[0]) for r in rows],
+            "per_rank_busy_s": busy,
+            "per_rank_restarts": [int(r[4]) for r in rows],
+            "idle_fraction": 1.0 - (sum(busy) / len(busy)) / max(max(busy), 1e-12),
+            "exchange_and_select_s": wall - max(busy),
+            "redo_fraction": (sum(r[6] for r in rows) / sum(r[5] for r in rows)) if sum(r[5] for r in rows) else None,
+            "exact_line_search_share": (sum(r[7] for r in rows) / max(1.0, sum(r[9] for r in rows))),
+            "best_score": best["score"],
+            "model_sha1": hashlib.sha1(json.dumps(model.to_dict(), sort_keys=True).encode()).hexdigest(),
+        }
+        e2e_top = e2e["e2e_evals_per_s"]
     else:
-        allr = mine
-    allr.sort(key=lambda r: r["restart_id"])
-    best_model = native.select_model(allr, False)
-    collective_ms = (time.perf_counter() - t0) * 1e3
-    best_score = max(r["score"] for r in allr)
+        e2e_top = None
 
     if rank == 0:
         b_eval = n * (4 * d + 8)  # algorithmic bytes per evaluate_mean
-        # dominant kernel: the bound-and-verify line search (the exact kernel only recomputes the pairs it
+        # dominant kernel: the bound-and-verify line search (the exact kernels only recompute the pairs it
         # could not verify); FR_LS_EXACT=1 runs measure the exact kernel instead
-        dom = next((k for k in ("linesearch_verify_kernel", "rr_verify_kernel", "rank_metric_kernel") if k in prof),
-                   "linesearch_ndcg_kernel")
+        dom = next((k for k in ("linesearch_verify_kernel", "fullrank_verify_kernel", "rr_verify_kernel", "rank_metric_kernel")
+                    if k in prof), "linesearch_ndcg_kernel")
         ls = prof.get(dom, {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
         exact = prof.get("linesearch_ndcg_kernel", {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
         evals_per_launch = (raw / max(1, ls["launches"])) if ls["launches"] else 0.0
-        avg_s = ls["avg_ms"] * 1e-3
-        achieved = (b_eval * evals_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0
-        # PMC figures (profiles/hbm_traffic.json, collected by tools/pmc_bench.sh on THIS command): per line group of
-        # a launch, separately for the timed (pipelined, ~restarts/3 groups per launch) and the isolated launches
-        # -- the instruction count falls as training proceeds (fewer documents enter a top-k list once the model
-        # ranks the relevant ones first), so each kind of launch is priced with its own count.
-        traffic = None
-        valu_insts = None
-        iso_valu_insts = None
-        pmc_busy_frac = pmc_clock = None
         groups_per_launch = evals_per_launch / 51.0
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath)).get(args.shape, {})
-                pmc_busy_frac = tj.get("bench_timed_valu_issue_frac_of_busy_cycles")
-                pmc_clock = tj.get("bench_timed_clock_ghz")
-                if dom == "linesearch_verify_kernel" and "bench_timed_valu_insts_per_group" in tj:
-                    valu_insts = tj["bench_timed_valu_insts_per_group"] * groups_per_launch
-                    iso_valu_insts = tj["bench_isolated_valu_insts_per_group"] * args.restarts_per_gpu
-                    traffic = tj["bench_timed_bytes_per_group"] * groups_per_launch
-                else:
-                    scale = groups_per_launch / float(tj.get("pmc_groups_per_launch", 32))
-                    traffic = tj.get(dom + "_bytes_per_launch")
-                    traffic = traffic * scale if traffic else None
-                    valu_insts = tj.get(dom + "_valu_insts_per_launch")
-                    valu_insts = valu_insts * scale if valu_insts else None
-                    iso_valu_insts = valu_insts / groups_per_launch * args.restarts_per_gpu if valu_insts else None
-            except Exception:
-                traffic = valu_insts = iso_valu_insts = None
-        vstats = st.get("stats", {})
-        vp, vr = float(vstats.get("verify_pairs", 0)), float(vstats.get("verify_redone", 0))
-        # FP64 adds the exact ordered dot products would need (what the exact kernel is bound by)
-        adds_per_launch = n * args.restarts_per_gpu * 51 * (d - 1) / 2.0  # avg shared prefix = half the features
+        step_s = elapsed_max / max(1, args.steps)
+        evals_per_step = raw / max(1, args.steps)
+        headline = (args.data == "mslr" and args.measure == "ndcg@10")
+        tj, pmc_meta = load_pmc(args.shape, headline and dom == "linesearch_verify_kernel")
+
+        # -- roofline from the ISOLATED launch (nothing else on the device): algorithmic bytes of the evaluations one
+        #    launch produces / its HIP-event duration
+        iso_k = iso.get(dom) if iso else None
+        if iso_k and iso_k["launches"]:
+            iso_evals_per_launch = iso_evals / iso_k["launches"]
+            iso_s = iso_k["avg_ms"] * 1e-3
+            timing = "isolated lock-step launches after the timed region (one per step, nothing else on the device)"
+        else:  # FR_LS_PIPELINE was set by the caller: the timed launches are what there is
+            iso_evals_per_launch, iso_s = evals_per_launch, ls["avg_ms"] * 1e-3
+            timing = "timed launches (FR_LS_PIPELINE set by the caller)"
+        iso_groups = iso_evals_per_launch / 51.0
+        achieved = (b_eval * iso_evals_per_launch / iso_s / 1e9) if iso_s > 0 else 0.0
+        effective = b_eval * evals_per_step / step_s / 1e9 if step_s > 0 else 0.0
+        traffic_iso = tj.get("bench_isolated_bytes_per_group")
+        traffic_iso = traffic_iso * iso_groups if traffic_iso else None
+        traffic_step = tj.get("bench_timed_bytes_per_group")
+        traffic_step = traffic_step * evals_per_step / 51.0 if traffic_step else None
+        roofline = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic_iso,
+            "kernel": dom,
+            "timing": timing,
+            "avg_launch_ms": iso_s * 1e3,
+            "launches": iso_k["launches"] if iso_k else ls["launches"],
+            "evals_per_launch": iso_evals_per_launch,
+            "algorithmic_bytes_per_launch": b_eval * iso_evals_per_launch,
+            # SURVEY 8(d) formula on the whole timed step (all launches, gaps, host share): value x B_eval / peak
+            "effective_frac": effective / HBM_PEAK_GBS,
+            # real HBM bytes (PMC, static -- see `pmc`) over the launch / over the step, against the peak
+            "hbm_frac_measured": (traffic_iso / iso_s / 1e9 / HBM_PEAK_GBS) if (traffic_iso and iso_s > 0) else None,
+            "hbm_frac_measured_step": (traffic_step / step_s / 1e9 / HBM_PEAK_GBS) if (traffic_step and step_s > 0) else None,
+            "traffic_per_step": traffic_step,
+            "note": "batched: one pass over the resident sums and ONE feature column serves the 51 candidates of a line "
+                    "group, so the algorithmic (per-eval, whole-matrix) bytes exceed real HBM traffic by construction and "
+                    "frac >> 1 is not evidence of kernel quality; hbm_frac_measured and limiter are",
+        }
+
+        # -- what actually binds the kernel: VALU issue.  Wave-level instruction counts are PMC constants (see `pmc`).
+        def valu_block(insts_per_group, mix, groups, seconds):
+            """utilisation of the VALU issue slots: every wave instruction priced at 4 cycles (f64 rate; an upper
+            bound) and, when the instruction-class counters were captured, f64-class instructions at 4 and the
+            rest (32-bit integer / bit-field / convert / moves) at 2 (MI355X_MICROARCH.md: a wave issues a 32-bit
+            VALU instruction over 2 cycles)."""
+            if not insts_per_group or seconds <= 0:
+                return None
+            total = insts_per_group * groups
+            slots = N_SIMD * CLOCK_HZ * seconds
+            out = {"wave_insts": total, "frac_all_at_4_cycles": total * 4.0 / slots}
+            if mix:
+                f64 = mix.get("f64_class_per_group", 0.0) * groups
+                out["f64_class_wave_insts"] = f64
+                out["frac_f64_at_4_rest_at_2"] = (f64 * 4.0 + (total - f64) * 2.0) / slots
+            return out
+
+        limiter = None
+        if dom == "linesearch_verify_kernel":
+            limiter = {
+                "bound": "valu_issue",
+                "unit": "fraction of 1024 SIMDs x 2.4 GHz issue cycles",
+                "isolated_launch": valu_block(tj.get("bench_isolated_valu_insts_per_group"), tj.get("bench_isolated_valu_mix"),
+                                              iso_groups, iso_s),
+                "timed_step": valu_block(tj.get("bench_timed_valu_insts_per_group"), tj.get("bench_timed_valu_mix"),
+                                         evals_per_step / 51.0, step_s),
+                # measured by the SQ counters of the PMC pass itself (no pricing model): VALU-active quad-cycles over the
+                # cycles the SIMDs were busy, and the clock those busy cycles imply (the chip runs this FP64 load at
+                # ~1.9 GHz, so the 2.4 GHz slots above are not all reachable)
+                "valu_active_frac_of_busy_cycles": tj.get("bench_isolated_valu_active_frac_of_busy_cycles"),
+                "valu_issue_frac_of_busy_cycles_all_at_4": tj.get("bench_isolated_valu_issue_frac_of_busy_cycles"),
+                "clock_ghz_under_load": tj.get("bench_isolated_clock_ghz"),
+                "frac": None,
+                "note": "bound-and-verify kernel on resident sums: three operations per document and restart for the "
+                        "base dot product, then a per-document loop over the tile in candidate lanes (LDS broadcast, "
+                        "FMA, compare; min/max chain for documents that enter a list); VALU-issue bound, "
+                        "see DESIGN.md section 4",
+            }
+            il = limiter["isolated_launch"]
+            if il:
+                limiter["frac"] = il.get("frac_f64_at_4_rest_at_2", il["frac_all_at_4_cycles"])
+        elif dom in ("linesearch_ndcg_kernel",):
+            adds_per_launch = n * iso_groups * 51 * (d - 1) / 2.0  # avg shared prefix = half the features
+            limiter = {
+                "bound": "fp64_valu_add",
+                "achieved": (adds_per_launch / iso_s / 1e12) if iso_s > 0 else 0.0,
+                "peak": FP64_VALU_PEAK_TADDS,
+                "unit": "Tadd/s",
+                "frac": (adds_per_launch / iso_s / 1e12 / FP64_VALU_PEAK_TADDS) if iso_s > 0 else 0.0,
+                "measured_ceiling": 35.4,  # pure v_add_f64 stream on this chip, tools/ubench/dpadd.hip
+            }
+        vp = float(s1["verify_pairs"] - s0["verify_pairs"])
+        vr = float(s1["verify_redone"] - s0["verify_redone"])
         out = {
-            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape" if args.measure == "ndcg@10"
-            else "coordinate-ascent {} evals/sec on MSLR-WEB30K shape (side measurement)".format(args.measure),
+            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape" if headline
+            else "coordinate-ascent {} evals/sec on MSLR-WEB30K shape, data={} (side measurement)".format(args.measure, args.data),
             "value": useful_all / elapsed_max,
             "unit": "evals/s",
             "n_gpus": world,
@@ -315,90 +496,44 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if args.data == "mslr" else "synthetic ({})".format(args.data),
             "config": {
                 "workload": "synthetic MSLR-WEB{} shape: {} docs x {} features x {} queries, coordinate ascent "
-                            "{}, {} restarts/GPU x 25 steps/coord (configs[2])".format(
-                                args.shape.upper(), n, d, q, args.measure.upper() if args.measure.startswith("ndcg") else args.measure, args.restarts_per_gpu),
+                            "{}, {} x 25 steps/coord (configs[{}])".format(
+                                args.shape.upper(), n, d, q, args.measure.upper() if args.measure.startswith("ndcg") else args.measure,
+                                "{} restarts in total".format(R) if strong else "{} restarts/GPU".format(args.restarts_per_gpu),
+                                3 if R == 256 and world == 8 else 2),
                 "restarts_total": R,
                 "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
-                "evals_per_step_per_gpu": raw / max(1, args.steps),
+                "evals_per_step_per_gpu": evals_per_step,
                 "launches_per_step": ls["launches"] / max(1, args.steps),
                 "groups_per_launch": groups_per_launch,
+                "jobs_finished_inside_timed_region": jobs["finished"],
             },
             "raw_evals_per_s": raw_all / elapsed_max,
             "useful_fraction": useful_all / max(1.0, raw_all),
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": dom,
-                "avg_launch_ms": ls["avg_ms"],
-                "launches": ls["launches"],
-                "algorithmic_bytes_per_launch": b_eval * evals_per_launch,
-                "note": "batched: one pass over X serves every candidate of a launch, so the algorithmic "
-                        "(per-eval) bytes exceed real HBM traffic and frac can exceed 1; see limiter.  Launches of "
-                        "the timed region overlap (three streams): avg_launch_ms includes time shared with the "
-                        "neighbouring launches",
-            },
-            "limiter": ({
-                "bound": "valu_issue",
-                # wave-level VALU instructions of the dominant kernel (rocprofv3 SQ_INSTS_VALU per (run, group) pair,
-                # profiles/hbm_traffic.json, first ticks of a run) issued over the WHOLE timed region -- launch gaps,
-                # the small kernels and the host's share included -- against 1024 SIMDs x one VALU instruction per
-                # 4 cycles at 2.4 GHz.  The timed launches overlap at their ends (three streams), so their own
-                # HIP-event durations (per_launch_overlapped) add up to more than the elapsed time; isolated_launch
-                # is the same kernel alone on the device.
-                "achieved": (valu_insts * ls["launches"] / elapsed_max / 1e9) if valu_insts else None,
-                "peak": 1024 * 2.4e9 / 4 / 1e9,
-                "unit": "G wave-instr/s",
-                "frac": (valu_insts * ls["launches"] / elapsed_max / (1024 * 2.4e9 / 4)) if valu_insts else None,
-                # from the PMC pass (static, profiles/hbm_traffic.json): the kernel's VALU instructions x 4 cycles over the
-                # SIMD cycles it was actually busy for (SQ_BUSY_CYCLES), and the clock those cycles imply -- the chip
-                # runs this FP64 load at ~1.9 GHz, so the 2.4 GHz peak above is not reachable by any instruction mix
-                "valu_issue_frac_of_busy_cycles": pmc_busy_frac,
-                "clock_ghz_under_load": pmc_clock,
-                "per_launch_overlapped": {
-                    "avg_launch_ms": ls["avg_ms"],
-                    "groups_per_launch": groups_per_launch,
-                    "frac": (valu_insts / avg_s / (1024 * 2.4e9 / 4)) if (valu_insts and avg_s > 0) else None,
-                },
-                "isolated_launch": ({
-                    "avg_launch_ms": iso[dom]["avg_ms"],
-                    "launches": iso[dom]["launches"],
-                    "groups_per_launch": args.restarts_per_gpu,
-                    "frac": (iso_valu_insts / (iso[dom]["avg_ms"] * 1e-3) / (1024 * 2.4e9 / 4))
-                    if (iso_valu_insts and iso[dom]["avg_ms"] > 0) else None,
-                    "note": "lock-step steps after the timed region (FR_LS_PIPELINE=0): one launch per step, no overlap",
-                } if (iso and dom in iso) else None),
-                "note": "bound-and-verify kernel on resident sums: three operations per document and restart for the "
-                        "base dot product, then a per-document loop over the tile in candidate lanes (LDS broadcast, "
-                        "FMA, compare; min/max chain for documents that enter a list); VALU-issue bound, "
-                        "see DESIGN.md section 4",
-                "verify_pairs": vp,
-                "verify_redone": vr,
-                "redo_fraction": (vr / vp) if vp else None,
+            "e2e_evals_per_s": e2e_top,
+            "roofline": roofline,
+            "limiter": limiter,
+            "pmc": pmc_meta,
+            "verify": {
+                "pairs": vp, "redone": vr, "redo_fraction": (vr / vp) if vp else None,
+                "ticks": s1["ticks"] - s0["ticks"],
+                "line_searches": s1["line_searches"] - s0["line_searches"],
+                # line searches evaluated by the exact kernels alone (after one with > 25 % redone pairs)
+                "exact_line_search_share": (s1["exact_ticks"] - s0["exact_ticks"]) / max(1, s1["line_searches"] - s0["line_searches"]),
                 "exact_kernel_ms_per_step": exact["total_ms"] / max(1, args.steps),
-            } if dom == "linesearch_verify_kernel" else {
-                "bound": "fp64_valu_add",
-                "achieved": (adds_per_launch / avg_s / 1e12) if avg_s > 0 else 0.0,
-                "peak": FP64_VALU_PEAK_TADDS,
-                "unit": "Tadd/s",
-                "frac": (adds_per_launch / avg_s / 1e12 / FP64_VALU_PEAK_TADDS) if avg_s > 0 else 0.0,
-                "measured_ceiling": 35.4,  # pure v_add_f64 stream on this chip, tools/ubench/dpadd.hip
-            }),
+            },
+            "per_launch_overlapped": {"avg_launch_ms": ls["avg_ms"], "launches": ls["launches"],
+                                      "note": "HIP-event durations of the timed launches; three are in flight, so they overlap"},
             "kernels_ms": {k: v["total_ms"] for k, v in prof.items()},
-            "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "final_allgather_select_ms": collective_ms,
-                      "best_score_so_far": best_score},
+            "e2e": e2e,
+            "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "best_score_so_far": best_so_far},
         }
         if world == 1 and not args.no_cpu_baseline:
-            del run
             out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds, args.measure)
         print(json.dumps(out))
         sys.stdout.flush()

@@ -143,6 +143,8 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("restarts", Value::uint(s.restarts));
     o.set("verify_pairs", Value::uint(s.verify_pairs));
     o.set("verify_redone", Value::uint(s.verify_redone));
+    o.set("exact_ticks", Value::uint(s.exact_ticks));
+    o.set("line_searches", Value::uint(s.line_searches));
     return o;
 }
 

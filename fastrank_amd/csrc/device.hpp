@@ -140,6 +140,8 @@ class DeviceDataset {
     const std::vector<double>& column_absmax() const;  // per-column max |x|
     // running totals: (run, group) pairs given to the bound-and-verify kernel / recomputed exactly
     void verify_counters(unsigned long long* pairs, unsigned long long* redone) const;
+    // line searches that skipped bound-and-verify because a recent one had > 25 % of its pairs redone
+    unsigned long long exact_fallbacks() const;
     // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----
     bool fullrank_supported(int measure, int64_t depth) const;
     bool linesearch_fullrank(int measure, int64_t depth, const double* norms, const std::vector<LineGroup>& groups,

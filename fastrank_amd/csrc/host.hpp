@@ -682,6 +682,17 @@ struct TrainStats {
     // fused_linesearch: (run, group) pairs evaluated by the bound-and-verify kernel, and how many of
     // them it could not verify (recomputed by the exact kernel)
     uint64_t verify_pairs = 0, verify_redone = 0;
+    uint64_t line_searches = 0;  // batched line searches submitted (one per tick in lock step, one per set and tick when pipelined)
+    uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone after a tick with > 25 % redone pairs
+};
+
+// adds the exact-only line searches of a scope to the trainer's statistics (also when the scope unwinds)
+struct ExactTickCount {
+    frdev::DeviceDataset& dev;
+    TrainStats& st;
+    unsigned long long base;
+    ExactTickCount(frdev::DeviceDataset& d, TrainStats& s) : dev(d), st(s), base(d.exact_fallbacks()) {}
+    ~ExactTickCount() { st.exact_ticks += dev.exact_fallbacks() - base; }
 };
 
 // coordinate_ascent.rs:72-82
@@ -834,8 +845,10 @@ class CATrainer {
     // One lock-step tick.  Returns false when every restart had already converged.
     bool tick() {
         frdev::DeviceDataset& dev = view_->device();
+        ExactTickCount etc_(dev, stats_);
         size_t gen_B = 0;
         if (!build_groups(-1, groups_, &gen_B)) return false;
+        stats_.line_searches++;
         dev.set_sums_only((bool)shard_.allreduce);  // the dataset object may be shared with other callers
         if (fused_) {
             std::string _err;
@@ -889,6 +902,7 @@ class CATrainer {
             return alive;
         }
         frdev::DeviceDataset& dev = view_->device();
+        ExactTickCount etc_(dev, stats_);
         constexpr int MAXP = frdev::DeviceDataset::LINESEARCH_CONTEXTS;
         uint64_t steps[MAXP] = {};
         bool inflight[MAXP] = {};
@@ -896,6 +910,7 @@ class CATrainer {
         auto submit = [&](int h) {
             size_t unused = 0;
             if (steps[h] >= max_ticks || !build_groups(h, groups_h_[h], &unused)) return;
+            stats_.line_searches++;
             dev.set_sums_only(false);
             std::string _err;
             ready[h] = false;

@@ -773,7 +773,7 @@ def test_redo_list_longer_than_the_first_exact_launch():
     qid = np.repeat(np.arange(1, nq + 1), per)
     X[1::2] = X[0::2]  # pairs of identical rows: exact ties for every weight vector
     y[0::2] = 2.0      # the duplicated rows are the relevant ones, so the ties sit among the best documents
-    y[1::2] = 2.0
+    y[1::2] = 1.0      # ... with different gains: the reference's gain / id tie-break decides their order
     X[0::2, 0] += 5.0
     X[1::2, 0] += 5.0
     g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
@@ -793,7 +793,11 @@ def test_redo_list_longer_than_the_first_exact_launch():
     p = req.params
     p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 3, True, 4, 3
     shard, st = _train_stats(g, req)
-    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@5", p.to_dict(), threads=2)
+    try:
+        o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)  # 700 queries: the mean's summation shape matters
+        exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@5", p.to_dict(), threads=2)
+    finally:
+        o.set_mean_segment(0)
     assert err == 0
     for r in shard["restarts"]:
         assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
@@ -852,6 +856,70 @@ def test_verify_kernel_near_ties_below_the_error_bound():
         w[0] = cands[0][ci]
         exp, _ = c.metric_from_scores("ndcg@5", c.score_linear(w))
         assert np.array_equal(pq[:, ci], exp), ci
+
+
+def _with_same_label_duplicates(seed, n, d, nq, frac=0.1):
+    """Duplicated documents that carry their source's label: exact score ties for every weight vector, none of
+    which the reference's tie-break has to decide between gain classes (the continuous columns keep
+    coincidental ties between different documents out)."""
+    rng = np.random.default_rng(seed)
+    X, y, qid = synth_dataset(seed, n, d, nq, max_len=200)
+    for i in np.nonzero(rng.random(len(y)) < frac)[0]:
+        if i > 0 and qid[i - 1] == qid[i]:
+            X[i], y[i] = X[i - 1], y[i - 1]
+    return X, y, qid
+
+
+def test_verify_kernel_accepts_ties_inside_one_gain_class(monkeypatch):
+    """Tied documents of ONE gain class may come in either order without changing DCG@k, so the verify kernel
+    keeps such pairs (kernels_verify.inc); with more keys per list (XS = 2, 3; raised by the host while many
+    pairs fail) a tied pair / triple may also straddle the cut.  The trajectory is the oracle's in every mode,
+    and the share of pairs sent to the exact kernel falls with XS."""
+    X, y, qid = _with_same_label_duplicates(91, 9000, 10, 90)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 23, True, 4, 5
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+    assert err == 0
+    fracs = {}
+    for xs in ("1", "2", "3", ""):
+        if xs:
+            monkeypatch.setenv("FR_VERIFY_XS", xs)
+        else:
+            monkeypatch.delenv("FR_VERIFY_XS", raising=False)
+        shard, st = _train_stats(g, req)
+        for r in shard["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), xs
+        assert st["useful_evals"] == int(exp_e.sum())
+        fracs[xs] = (st["verify_redone"] / max(1, st["verify_pairs"]), st["exact_ticks"], st["line_searches"])
+    print("redo fraction / exact-only line searches / line searches by FR_VERIFY_XS:", fracs)
+    if _verify_path_on(resident_needed=True):
+        assert fracs["1"][0] > fracs["2"][0] > fracs["3"][0] > 0.0, fracs
+        assert fracs["3"][0] < 0.2, fracs
+        assert fracs[""][0] < fracs["1"][0] and fracs[""][1] <= fracs["1"][1], fracs  # adaptive: raised after the first line searches
+
+
+def test_mrr_verify_ignores_ties_among_relevant_documents():
+    """Reciprocal rank: near-ties and exact ties between RELEVANT documents need no resolving (whichever comes
+    first has the same documents before it); only a non-relevant document close to the best relevant key sends
+    the pair to rr_exact_kernel (kernels_rr.inc)."""
+    X, y, qid = _with_same_label_duplicates(93, 9000, 10, 90)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "mrr"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 29, True, 3, 5
+    shard, st = _train_stats(g, req)
+    exp_s, exp_w, exp_e, err = c.ca_learn("mrr", p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["useful_evals"] == int(exp_e.sum())
+    if _verify_path_on(resident_needed=True):
+        assert st["verify_pairs"] > 0
+        assert st["verify_redone"] / st["verify_pairs"] < 0.25, st
 
 
 @pytest.mark.parametrize("env", [{}, {"FR_RESIDENT_REFRESH": "2"}, {"FR_LS_RESIDENT": "0"}, {"FR_VERIFY_GW": "4"},

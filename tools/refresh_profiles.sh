@@ -41,8 +41,21 @@ PY
 python tools/treebench.py --reps 5 2>&1 | tail -1 > "$OUT/${TAG}_treebench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_tree" -o p -- python tools/treebench.py --reps 5 --check 0 > "$OUT/kt_tree.log" 2>&1
 cp "$OUT"/kt_tree/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt_tree/*/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv"
+# the reference's default measure (depth-less NDCG) and MAP: sort-and-verify on resident sums
+{ for m in ndcg map; do python tools/train_e2e.py --measure $m --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1; done; } > "$OUT/${TAG}_train_fullrank_30k.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_full" -o p -- python tools/train_e2e.py --measure ndcg --shape 30k --restarts 32 --max-ticks 136 > "$OUT/kt_full.log" 2>&1
+cp "$OUT"/kt_full/*kernel_stats.csv "$OUT/${TAG}_fullrank_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt_full/*/*kernel_stats.csv "$OUT/${TAG}_fullrank_kernel_stats.csv"
+# side measurements on tie-heavy and on hard data: bench line + a whole run each
+for kind in ties hard; do
+  python bench.py --steps 20 --warmup 3 --data $kind --no-cpu-baseline 2> "$OUT/bench_$kind.err" | tail -1 > "$OUT/${TAG}_bench_$kind.json"
+done
+# the N>1 path on one GPU (gloo, both ranks on device 0): strong scaling of a 32-restart job, static and work stealing
+for steal in 0 4; do
+  FR_BENCH_DEVICE=0 FR_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 2 --steps 10 --warmup 2 --shape 10k --restarts-total 32 --steal-block $steal 2> "$OUT/bench_2rank_$steal.err" | tail -1 > "$OUT/${TAG}_bench_2rank_1gpu_steal$steal.json"
+done
 python tools/train_e2e.py 2>&1 | tail -1 > "$OUT/${TAG}_train_e2e_10k.json"
 python tools/train_e2e.py --measure mrr --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1 > "$OUT/${TAG}_train_mrr_30k.json"
 { python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; FR_LS_EXACT=1 python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; } > "$OUT/${TAG}_train_e2e_30k.json"
-rm -rf "$OUT/kt" "$OUT/kt_tree"
+rm -rf "$OUT/kt" "$OUT/kt_tree" "$OUT/kt_full"
 ls -la "$OUT"

@@ -22,11 +22,12 @@ def main():
     ap.add_argument("--shape", default="10k")
     ap.add_argument("--restarts", type=int, default=8)
     ap.add_argument("--measure", default="ndcg@10")
+    ap.add_argument("--data", default="mslr", choices=bench.DATA_KINDS)
     ap.add_argument("--max-ticks", type=int, default=100000)
     ap.add_argument("--profile", action="store_true", help="HIP-event time per kernel (use with FR_LS_PIPELINE=0: overlapping launches inflate it)")
     args = ap.parse_args()
     n, d, q, seed = bench.SHAPES[args.shape]
-    X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
+    X, y, qid = bench.gen_mslr_shaped(seed, n, d, q, args.data)
     ds = fr.CDataset.from_numpy(X, y, qid)
     req = fr.TrainRequest.coordinate_ascent()
     req.measure = args.measure
@@ -54,7 +55,9 @@ def main():
     st = run.state()
     model = native.select_model(st["restarts"], False)
     mean = float(np.mean(native.evaluate_dense(model, ds, args.measure)[1]))
-    print(json.dumps({"shape": args.shape, "restarts": args.restarts, "measure": args.measure, "finished": run.finished,
+    vp, vr = st["stats"].get("verify_pairs") or 0, st["stats"].get("verify_redone") or 0
+    print(json.dumps({"shape": args.shape, "data": args.data, "redo_fraction": (vr / vp) if vp else None,
+                      "exact_line_search_share": (st["stats"].get("exact_ticks") or 0) / max(1, st["stats"].get("line_searches") or 1), "restarts": args.restarts, "measure": args.measure, "finished": run.finished,
                       "ticks": ticks, "train_wall_s": wall, "upload_init_s": t_init,
                       "useful_evals": st["stats"]["useful_evals"], "raw_evals": st["stats"]["raw_evals"],
                       "useful_evals_per_s": st["stats"]["useful_evals"] / wall, "final_mean": mean,
