@@ -471,9 +471,19 @@ def main():
                         "FMA, compare; min/max chain for documents that enter a list); VALU-issue bound, "
                         "see DESIGN.md section 4",
             }
+            # `frac`: share of the 1024 SIMDs x 2.4 GHz issue cycles of an isolated launch in which the VALU was active.
+            # Measured: SQ_ACTIVE_INST_VALU (quad-cycles) over SQ_BUSY_CYCLES, scaled by the clock the busy cycles
+            # imply.  It agrees with the instruction count priced at 4 cycles each (frac_all_at_4_cycles); the
+            # instruction-class counters classify only 13 % of the kernel's VALU instructions (v_min/max/cmp_f64 are
+            # in none of them), so frac_f64_at_4_rest_at_2 is a LOWER bound on issue utilisation, not an estimate.
+            act, clk = limiter["valu_active_frac_of_busy_cycles"], limiter["clock_ghz_under_load"]
             il = limiter["isolated_launch"]
-            if il:
-                limiter["frac"] = il.get("frac_f64_at_4_rest_at_2", il["frac_all_at_4_cycles"])
+            if act and clk:
+                limiter["frac"] = act * clk * 1e9 / CLOCK_HZ
+                limiter["frac_source"] = "SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES x clock_under_load / 2.4 GHz"
+            elif il:
+                limiter["frac"] = il["frac_all_at_4_cycles"]
+                limiter["frac_source"] = "SQ_INSTS_VALU x 4 cycles"
         elif dom in ("linesearch_ndcg_kernel",):
             adds_per_launch = n * iso_groups * 51 * (d - 1) / 2.0  # avg shared prefix = half the features
             limiter = {

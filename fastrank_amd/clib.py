@@ -87,6 +87,7 @@ def _load():
         "fr_profile_enable": (None, [C.c_int]),
         "fr_profile_reset": (None, []),
         "fr_profile_json": (vp, []),
+        "fr_debug_resident_bound": (C.c_double, [C.c_int, C.c_double, C.c_double, C.c_double]),
         "fr_synchronize": (C.c_int, []),
     }
     for name, (restype, argtypes) in sigs.items():

@@ -1,5 +1,6 @@
 // extern "C" boundary of libfastrank_amd.so -- see include/fastrank.h for the contract and the
 // reference file:line each symbol replaces (src/lib.rs, src/ffi.rs, src/json_api.rs).
+#include <limits>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -145,6 +146,8 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("verify_redone", Value::uint(s.verify_redone));
     o.set("exact_ticks", Value::uint(s.exact_ticks));
     o.set("line_searches", Value::uint(s.line_searches));
+    o.set("audit_values", Value::uint(s.audit_values));
+    o.set("audit_mismatches", Value::uint(s.audit_mismatches));
     return o;
 }
 
@@ -896,6 +899,15 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
 
 void fr_profile_enable(int on) { frdev::profile_enable(on != 0); }
 void fr_profile_reset(void) { frdev::profile_reset(); }
+
+double fr_debug_resident_bound(int which, double a, double b, double c) {
+    switch (which) {
+        case 0: return frdev::resident_err_refresh((uint32_t)a, b);
+        case 1: return frdev::resident_err_update(a, b, c);
+        case 2: return frdev::resident_eps_extra(a, b, c);
+        default: return std::numeric_limits<double>::quiet_NaN();
+    }
+}
 
 const void* fr_profile_json(void) {
     return json_call([&]() {

@@ -20,6 +20,20 @@ namespace frdev {
 
 enum Measure : int { M_NDCG = 0, M_AP = 1, M_RR = 2 };
 
+// Error bound E >= |R - sum_j x_j v_j| of a trainer's resident sums, u = 2^-53, T from column
+// maxima.  One place for the constants: the trainer (host.hpp), compute_eps2 (device_dataset.inc) and the CPU test
+// that replays the device's update arithmetic against extended precision (tests/test_error_bound.py, through
+// fr_debug_resident_bound) all use these.
+//   after an exact refresh (score_linear: ordered unfused f64 sums of D products): gamma_D * T
+inline double resident_err_refresh(uint32_t d, double T) { return 1.1 * (double)(d + 1) * 0x1p-53 * T; }
+//   after R' = fma(x_f, cand, fma(-x_f, base_f, R * fl(1/norm))) with base = fl(v / norm), v' = base with [f] = cand:
+//   the old error shrinks by 1/norm; the separately rounded divisions of l1_normalize (u T), the reciprocal and the
+//   product R * inv (2 u T), and the two FMA roundings (u (|x_f base_f| + T) + u T) add at most 8 u T with
+//   T = |base_f| X_f + sum_j |v'_j| X_j
+inline double resident_err_update(double err, double norm, double T) { return 1.002 * err / norm + 8.0 * 0x1p-53 * T * (1.0 + 1e-6); }
+//   what A = fma(-x_f, base_f, R * fl(1/norm)) adds to a candidate's key error (T = sum_j |base_j| X_j incl. j = f)
+inline double resident_eps_extra(double err, double norm, double T) { return 1.01 * err / norm + 10.0 * 0x1p-53 * T; }
+
 // error bits raised by kernels (the reference panics in these cases)
 enum : int {
     FLAG_NAN_SCORE = 1,        // src/model.rs:49  "Model.predict -> NaN"
@@ -142,6 +156,8 @@ class DeviceDataset {
     void verify_counters(unsigned long long* pairs, unsigned long long* redone) const;
     // line searches that skipped bound-and-verify because a recent one had > 25 % of its pairs redone
     unsigned long long exact_fallbacks() const;
+    // FR_VERIFY_AUDIT=1: values re-derived by the exact kernel after a bound-and-verify line search / how many differed
+    void audit_counters(unsigned long long* values, unsigned long long* mismatches) const;
     // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----
     bool fullrank_supported(int measure, int64_t depth) const;
     bool linesearch_fullrank(int measure, int64_t depth, const double* norms, const std::vector<LineGroup>& groups,

@@ -683,6 +683,7 @@ struct TrainStats {
     // them it could not verify (recomputed by the exact kernel)
     uint64_t verify_pairs = 0, verify_redone = 0;
     uint64_t line_searches = 0;  // batched line searches submitted (one per tick in lock step, one per set and tick when pipelined)
+    uint64_t audit_values = 0, audit_mismatches = 0;  // FR_VERIFY_AUDIT=1 (see include/fastrank.h)
     uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone after a tick with > 25 % redone pairs
 };
 
@@ -690,9 +691,15 @@ struct TrainStats {
 struct ExactTickCount {
     frdev::DeviceDataset& dev;
     TrainStats& st;
-    unsigned long long base;
-    ExactTickCount(frdev::DeviceDataset& d, TrainStats& s) : dev(d), st(s), base(d.exact_fallbacks()) {}
-    ~ExactTickCount() { st.exact_ticks += dev.exact_fallbacks() - base; }
+    unsigned long long base, av0 = 0, am0 = 0;
+    ExactTickCount(frdev::DeviceDataset& d, TrainStats& s) : dev(d), st(s), base(d.exact_fallbacks()) { d.audit_counters(&av0, &am0); }
+    ~ExactTickCount() {
+        unsigned long long av1 = 0, am1 = 0;
+        dev.audit_counters(&av1, &am1);
+        st.exact_ticks += dev.exact_fallbacks() - base;
+        st.audit_values += av1 - av0;
+        st.audit_mismatches += am1 - am0;
+    }
 };
 
 // coordinate_ascent.rs:72-82
@@ -1103,7 +1110,7 @@ class CATrainer {
                 const std::vector<double>& X = dev.column_absmax();
                 double T = std::fabs(r.base[f]) * X[f];
                 for (size_t j = 0; j < d_; j++) T += std::fabs(r.best_w[j]) * X[j];
-                r.res_err = 1.002 * r.res_err / r.norm + 8.0 * std::ldexp(1.0, -53) * T * (1.0 + 1e-6);
+                r.res_err = frdev::resident_err_update(r.res_err, r.norm, T);
                 r.res_updates++;
                 r.pend = true;
                 r.pend_f = f;
@@ -1163,7 +1170,7 @@ class CATrainer {
                 }
                 double T = 0.0;
                 for (size_t j = 0; j < d_; j++) T += std::fabs(r.best_w[j]) * X[j];
-                r.res_err = 1.1 * (double)(d_ + 1) * std::ldexp(1.0, -53) * T;  // gamma_D * T of an ordered sum
+                r.res_err = frdev::resident_err_refresh((uint32_t)d_, T);  // gamma_D * T of an ordered sum
                 r.res_updates = 0;
                 r.pend = false;
             }

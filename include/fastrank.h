@@ -141,9 +141,12 @@ void fr_ca_free(void *trainer);
  * restarts_json: JSON list of {"restart_id","score","weights"}; returns a CModel. */
 const CResult *fr_select_model(const void *restarts_json, int output_ensemble);
 /* JSON stats of the most recent train_model / fr_train_model_shard call in this process:
- * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts","verify_pairs","verify_redone"}
+ * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts","verify_pairs","verify_redone",
+ *  "exact_ticks","line_searches","audit_values","audit_mismatches"}
  * (path: "fused_linesearch" | "fused_fullrank" | "generic_sort"; verify_*: (query, group) pairs evaluated by the
- * bound-and-verify kernels and how many of them were recomputed by the exact kernels). */
+ * bound-and-verify kernels and how many of them were recomputed by the exact kernels; exact_ticks of line_searches
+ * batched line searches went to the exact kernels alone; audit_*: with FR_VERIFY_AUDIT=1 every published NDCG@k
+ * value is recomputed by the exact kernel and compared bit for bit -- values compared / values that differed). */
 const void *fr_last_train_stats(void);
 
 /* Dense results without JSON.  out[i] = score of instance i (instances outside the dataset
@@ -182,6 +185,13 @@ void fr_profile_reset(void);
 const void *fr_profile_json(void);
 /* hipDeviceSynchronize; 0 on success. */
 int fr_synchronize(void);
+/* The constants of the resident-sum error bound the trainer and the bound-and-verify kernels use (DESIGN.md
+ * section 4a), so that a CPU test can replay the device's update arithmetic against extended precision with the
+ * product's own numbers.  which = 0: bound after an exact refresh (a = feature count, b = T);
+ * 1: bound after one incremental update (a = previous bound, b = norm, c = T);
+ * 2: the term a candidate key's error bound gains from the resident form (a = bound, b = norm, c = T).
+ * No device needed.  NaN for an unknown `which`. */
+double fr_debug_resident_bound(int which, double a, double b, double c);
 
 #ifdef __cplusplus
 }

@@ -805,3 +805,19 @@ long oracle_check_div_identity(int maxb) {
     }
     return bad;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Test helper (no reference counterpart): the DEVICE's incremental update of a resident  */
+/* sum, fastrank_amd/csrc/kernels_verify.inc phase S,                                     */
+/*   R' = fma(x_f, cand, fma(-x_f, base_f, R * inv)),   inv = fl(1 / norm),               */
+/* replayed on the CPU so that tests/test_error_bound.py can hold the trainer's error     */
+/* recurrence against extended precision.  (R * inv is rounded on its own:                 */
+/* -ffp-contract=off, like the device code.)                                               */
+/* ------------------------------------------------------------------------------------ */
+void oracle_resident_update(double *R, const float *xf, size_t n, double cand, double base_f, double inv) {
+    for (size_t i = 0; i < n; i++) {
+        const double x = (double)xf[i];
+        const double scaled = R[i] * inv;
+        R[i] = fma(x, cand, fma(-x, base_f, scaled));
+    }
+}

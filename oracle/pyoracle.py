@@ -84,6 +84,8 @@ def lib():
     L.oracle_check_div_identity.argtypes = [C.c_int]
     L.oracle_rand64_stream.argtypes = [u64, sz, vp]
     L.oracle_shuffle_with_seed.argtypes = [u64, vp, sz]
+    L.oracle_resident_update.restype = None
+    L.oracle_resident_update.argtypes = [vp, vp, sz, dbl, dbl, dbl]
     _lib = L
     return L
 
@@ -317,3 +319,10 @@ def shuffle_with_seed(seed, n):
 def check_div_identity(maxb: int) -> int:
     """Pairs 1 <= a <= b <= maxb where the 2-FMA quotient of kernels_fullverify.inc differs from a / b."""
     return int(lib().oracle_check_div_identity(int(maxb)))
+
+
+def resident_update(R, xf, cand, base_f, inv):
+    """In place: R <- fma(x_f, cand, fma(-x_f, base_f, R * inv)), the device's incremental update of a resident
+    sum (test helper, see fastrank_oracle.c)."""
+    assert R.dtype == np.float64 and xf.dtype == np.float32 and R.flags.c_contiguous and xf.flags.c_contiguous
+    lib().oracle_resident_update(_p(R), _p(xf), len(R), float(cand), float(base_f), float(inv))

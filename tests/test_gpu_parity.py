@@ -762,10 +762,11 @@ def test_verify_kernel_falls_back_on_ties_and_duplicates():
             assert np.array_equal(pq[:, gi * 64 + ci], exp), (gi, ci)
 
 
-def test_redo_list_longer_than_the_first_exact_launch():
-    """The exact kernel's first launch on the redo list has a fixed grid (512 pairs, compared with the count on
+def test_redo_list_longer_than_the_first_exact_launch(monkeypatch):
+    """The exact kernel's first launch on the redo list has a fixed grid (8192 pairs; 512 here, compared with the count on
     the device); the rest of a longer list is recomputed after the results came back.  Every query here has
     duplicated documents on top, so every (query, group) pair of 700 queries x 3 groups is on the list."""
+    monkeypatch.setenv("FR_REDO_GRID", "512")
     rng = np.random.default_rng(5)
     nq, per = 700, 14
     X = rng.random((nq * per, 6)).astype(np.float32)
@@ -920,6 +921,43 @@ def test_mrr_verify_ignores_ties_among_relevant_documents():
     if _verify_path_on(resident_needed=True):
         assert st["verify_pairs"] > 0
         assert st["verify_redone"] / st["verify_pairs"] < 0.25, st
+
+
+def _signed_heavy_tail_dataset(seed, n, d, nq):
+    """Adversarial for the resident-sum error bound: signed heavy-tail columns (cancellation),
+    columns of very different scale, small-integer columns (ties)."""
+    rng = np.random.default_rng(seed)
+    _, y, qid = synth_dataset(seed, n, d, nq, max_len=150)
+    X = rng.lognormal(0.0, 2.5, (n, d)) * rng.choice([-1.0, 1.0], (n, d))
+    X[:, ::5] = np.floor(rng.exponential(2.0, (n, len(range(0, d, 5)))))
+    X[:, 3::7] *= 1e-4
+    X[:, 1] += 0.5 * y * np.abs(X[:, 1]).mean()
+    return X.astype(np.float32), y, qid
+
+
+@pytest.mark.parametrize("measure", ["ndcg@10", "mrr", "ndcg"])
+def test_resident_sums_never_refreshed_on_adversarial_columns(measure, monkeypatch):
+    """FR_RESIDENT_REFRESH=100000: the resident sums are never re-derived exactly, so every accepted candidate of a
+    whole run adds to their drift and the host's error recurrence alone keeps the verification honest.  With
+    FR_VERIFY_AUDIT=1 every NDCG@k value the verify path publishes is also recomputed by the exact kernel and
+    compared bit for bit (audit_mismatches == 0)."""
+    monkeypatch.setenv("FR_RESIDENT_REFRESH", "100000")
+    monkeypatch.setenv("FR_VERIFY_AUDIT", "1")
+    X, y, qid = _signed_heavy_tail_dataset(201, 8000, 24, 80)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = measure
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 31, True, 4, 8
+    shard, st = _train_stats(g, req)   # to convergence
+    exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=2)
+    assert err == 0
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["useful_evals"] == int(exp_e.sum())
+    assert st["ticks"] > 3 * 24, "long accept chains wanted"
+    if measure == "ndcg@10" and _verify_path_on(resident_needed=True):
+        assert st["audit_values"] > 0 and st["audit_mismatches"] == 0, st
 
 
 @pytest.mark.parametrize("env", [{}, {"FR_RESIDENT_REFRESH": "2"}, {"FR_LS_RESIDENT": "0"}, {"FR_VERIFY_GW": "4"},

@@ -63,6 +63,7 @@ def main():
                       "useful_evals_per_s": st["stats"]["useful_evals"] / wall, "final_mean": mean,
                       "path": st["stats"]["path"], "verify_pairs": st["stats"].get("verify_pairs"),
                       "verify_redone": st["stats"].get("verify_redone"),
+                      "audit_values": st["stats"].get("audit_values"), "audit_mismatches": st["stats"].get("audit_mismatches"),
                       "restarts_sha1": hashlib.sha1(json.dumps(st["restarts"], sort_keys=True).encode()).hexdigest()}))
 
 
