@@ -620,7 +620,7 @@ def _ensemble(trees, weights):
     return fr.CModel.from_dict({"Ensemble": {"weights": list(weights), "models": [{"DecisionTree": t} for t in trees]}})
 
 
-@pytest.mark.parametrize("shape", ["", "256,1", "256,2", "256,4", "128,2", "128,4", "64,4"])
+@pytest.mark.parametrize("shape", ["", "256,1", "256,2", "256,4", "192,2", "192,4", "128,2", "128,4", "64,4"])
 def test_tree_kernel_block_shapes(mslr_small, shape, monkeypatch):
     """Every block shape of the LDS tree walk gives the oracle's scores bit for bit: 77 trees (so the
     last batches are ragged and padded), missing features (fid >= D reads 0.0), negative weights."""
