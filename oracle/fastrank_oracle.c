@@ -27,6 +27,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -820,4 +821,318 @@ void oracle_resident_update(double *R, const float *xf, size_t n, double cand, d
         const double scaled = R[i] * inv;
         R[i] = fma(x, cand, fma(-x, base_f, scaled));
     }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Random-forest training (src/random_forest.rs:22-408, src/sampling.rs:38-66,            */
+/* src/normalizers.rs:13-37, src/stats.rs:53-104)                                        */
+/*                                                                                       */
+/* Where the reference leaves an order unspecified this restatement fixes one, and the   */
+/* HIP path (fastrank_amd/csrc/rf_train.*) fixes the same:                                */
+/*  * the sampled instance list (sampling.rs:56-60 walks a HashMap): queries in this     */
+/*    dataset's query order, instances ascending inside a query;                         */
+/*  * instance_feature.sort_unstable() (random_forest.rs:230) orders equal feature       */
+/*    values arbitrarily: here equal values are ordered by the instance's index in the   */
+/*    tree's sampled instance list (children otherwise inherit the parent's sorted       */
+/*    order, random_forest.rs:277-283, which is what the leaf means are summed in);      */
+/*  * sort_unstable_by_key(importance) + last() (random_forest.rs:275-276,391-392):      */
+/*    among equal importances the LAST candidate in generation order wins (what the      */
+/*    insertion sort behind short slices does).                                          */
+/* Everything order-sensitive in floating point (leaf means, squared errors, Welford     */
+/* variances) is then summed in exactly the reference's association: sequentially over   */
+/* the (sorted) instance list.  DenseDataset semantics: every feature value is present.   */
+/* Seed -> sample: through Rand64, PARITY UNPINNED like the rest of the RNG (header).      */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    uint64_t seed;
+    uint32_t num_trees;
+    int32_t weight_trees;
+    int32_t split_method; /* 0 SquaredError, 1 BinaryGiniImpurity, 2 InformationGain, 3 TrueVarianceReduction (random_forest.rs:14-20) */
+    double instance_sampling_rate;
+    double feature_sampling_rate;
+    uint32_t min_leaf_support;
+    uint32_t split_candidates;
+    uint32_t max_depth;
+} oracle_rf_params;
+
+typedef struct {
+    int32_t *fid;
+    double *split;
+    int32_t *lhs, *rhs;
+    size_t n, cap;
+    int err; /* 1: out of node capacity, 2: the reference would have panicked (NaN importance, variance of < 2 labels) */
+} rf_out;
+
+typedef struct {
+    double v;
+    uint32_t pos;
+    uint32_t id;
+} rf_key;
+static int cmp_rf_key(const void *a, const void *b) {
+    const rf_key *x = (const rf_key *)a, *y = (const rf_key *)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+
+/* random_forest.rs:32-41 */
+static double rf_compute_output(const oracle_dataset *ds, const uint32_t *ids, size_t n) {
+    if (n == 0) return 0.0;
+    double gain_sum = 0.0;
+    for (size_t i = 0; i < n; i++) gain_sum += (double)(float)ds->y[ids[i]];
+    return gain_sum / (double)n;
+}
+/* random_forest.rs:42-51 */
+static double rf_squared_error(const oracle_dataset *ds, const uint32_t *ids, size_t n) {
+    double output = rf_compute_output(ds, ids, n);
+    double sum_sq_errors = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        double diff = output - (double)(float)ds->y[ids[i]];
+        sum_sq_errors += diff * diff;
+    }
+    return sum_sq_errors;
+}
+static size_t rf_positive(const oracle_dataset *ds, const uint32_t *ids, size_t n) {
+    size_t c = 0;
+    for (size_t i = 0; i < n; i++) c += ((float)ds->y[ids[i]] > 0.0f) ? 1 : 0;
+    return c;
+}
+/* random_forest.rs:52-66 */
+static double rf_gini(const oracle_dataset *ds, const uint32_t *ids, size_t n) {
+    if (n == 0) return 0.0;
+    double count = (double)n, positive = (double)rf_positive(ds, ids, n);
+    double p_yes = positive / count, p_no = (count - positive) / count;
+    return p_yes * (1.0 - p_yes) + p_no * (1.0 - p_no);
+}
+/* random_forest.rs:67-87 */
+static double rf_plogp(double x) { return x == 0.0 ? 0.0 : x * log2(x); }
+static double rf_entropy(const oracle_dataset *ds, const uint32_t *ids, size_t n) {
+    if (n == 0) return 0.0;
+    double count = (double)n, positive = (double)rf_positive(ds, ids, n);
+    double p_yes = positive / count, p_no = (count - positive) / count;
+    return -rf_plogp(p_yes) - rf_plogp(p_no);
+}
+/* stats.rs:66-104 (Welford); returns 0 when fewer than two elements (finish() -> None) */
+static int rf_variance(const oracle_dataset *ds, const uint32_t *ids, size_t n, double *var) {
+    double mean = 0.0, s = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        double x = (double)(float)ds->y[ids[i]];
+        if (i == 0) {
+            mean = x;
+            continue;
+        }
+        double old_mean = mean;
+        mean = old_mean + (x - old_mean) / (double)(i + 1);
+        s = s + (x - old_mean) * (x - mean);
+    }
+    if (n <= 1) return 0;
+    *var = s / (double)(n - 1);
+    return 1;
+}
+/* random_forest.rs:89-125 */
+static double rf_importance(const oracle_dataset *ds, int method, const uint32_t *lhs, size_t nl, const uint32_t *rhs,
+                            size_t nr, int *err) {
+    switch (method) {
+        case 0: return -(rf_squared_error(ds, lhs, nl) + rf_squared_error(ds, rhs, nr));
+        case 1: return -(rf_gini(ds, lhs, nl) * (double)nl + rf_gini(ds, rhs, nr) * (double)nr);
+        case 2: return -(rf_entropy(ds, lhs, nl) * (double)nl + rf_entropy(ds, rhs, nr) * (double)nr);
+        default: {
+            double vl = 0.0, vr = 0.0;
+            if (!rf_variance(ds, lhs, nl, &vl) || !rf_variance(ds, rhs, nr, &vr)) {
+                *err |= 2; /* label_stats(..).unwrap() on None */
+                return 0.0;
+            }
+            return -(vl * (double)nl + vr * (double)nr);
+        }
+    }
+}
+
+static int32_t rf_new_node(rf_out *o) {
+    if (o->n >= o->cap) {
+        o->err |= 1;
+        return -1;
+    }
+    return (int32_t)o->n++;
+}
+static int32_t rf_leaf(rf_out *o, double value) {
+    int32_t k = rf_new_node(o);
+    if (k < 0) return -1;
+    o->fid[k] = -1;
+    o->split[k] = value;
+    o->lhs[k] = o->rhs[k] = -1;
+    return k;
+}
+
+/* random_forest.rs:362-408 learn_recursive; returns the node index or -1 for Err(_) (the caller makes the leaf) */
+static int32_t rf_learn_recursive(const oracle_dataset *ds, const oracle_rf_params *p, const uint32_t *ids,
+                                  const uint32_t *ridx /* index of ids[i] in the tree's sampled list */, size_t n,
+                                  const uint32_t *fids, size_t nf, uint32_t depth, rf_out *o) {
+    if (nf == 0 || n == 0) return -1;                 /* StepDone */
+    if (depth >= p->max_depth) return -1;             /* DepthExceeded */
+    if (n < (size_t)p->min_leaf_support) return -1;   /* SplitTooSmall */
+    /* label_stats (random_forest.rs:218-221): None with < 2 instances, or all labels equal */
+    if (n <= 1) return -1;
+    float lmin = (float)ds->y[ids[0]], lmax = lmin;
+    for (size_t i = 1; i < n; i++) {
+        float g = (float)ds->y[ids[i]];
+        if (g < lmin) lmin = g;
+        if (g > lmax) lmax = g;
+    }
+    if (lmin == lmax) return -1; /* every feature's generate_split_candidate returns None -> NoFeatureSplitCandidates */
+    const uint32_t k = p->split_candidates;
+    rf_key *keys = (rf_key *)malloc(sizeof(rf_key) * n);
+    uint32_t *sorted = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *sorted_r = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *best_ids = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *best_r = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    int have = 0;
+    double best_imp = 0.0, best_split = 0.0;
+    size_t best_pos = 0;
+    uint32_t best_fid = 0;
+    for (size_t fi = 0; fi < nf; fi++) {
+        const uint32_t f = fids[fi];
+        /* FeatureStats (normalizers.rs:13-37): min / max over the node's instances; > 1 element (stats.rs:98-103) */
+        double fmin = 1.7976931348623157e308, fmax = -1.7976931348623157e308;
+        for (size_t i = 0; i < n; i++) {
+            double v = (double)ds->x[(size_t)ids[i] * ds->d + f];
+            keys[i].v = v;
+            keys[i].pos = ridx[i];
+            keys[i].id = ids[i];
+            if (fmax < v) fmax = v;
+            if (fmin > v) fmin = v;
+        }
+        const double range = fmax - fmin;
+        qsort(keys, n, sizeof(rf_key), cmp_rf_key); /* random_forest.rs:225-233 */
+        for (size_t i = 0; i < n; i++) sorted[i] = keys[i].id, sorted_r[i] = keys[i].pos;
+        /* random_forest.rs:236-273: k-1 thresholds, their positions, the surviving candidates' importances */
+        int fhave = 0;
+        double fbest_imp = 0.0, fbest_split = 0.0;
+        size_t fbest_pos = 0, ids_i = 0, prev_item = (size_t)-1;
+        for (uint32_t i = 1; i < k; i++) {
+            const double frac = (double)i / (double)k;
+            const double position = frac * range + fmin;
+            while (ids_i < n && keys[ids_i].v < position) ids_i++;
+            if (prev_item == ids_i) continue;
+            prev_item = ids_i;
+            const size_t nl = ids_i, nr = n - ids_i;
+            if (nl < (size_t)p->min_leaf_support || nr < (size_t)p->min_leaf_support) continue;
+            const double imp = rf_importance(ds, p->split_method, sorted, nl, sorted + nl, nr, &o->err);
+            if (isnan(imp)) o->err |= 2;
+            if (!fhave || imp >= fbest_imp) { /* sort_unstable_by_key(..).last() */
+                fhave = 1;
+                fbest_imp = imp;
+                fbest_split = position;
+                fbest_pos = ids_i;
+            }
+        }
+        if (fhave && (!have || fbest_imp >= best_imp)) { /* random_forest.rs:391-392 */
+            have = 1;
+            best_imp = fbest_imp;
+            best_split = fbest_split;
+            best_pos = fbest_pos;
+            best_fid = f;
+            memcpy(best_ids, sorted, sizeof(uint32_t) * n);
+            memcpy(best_r, sorted_r, sizeof(uint32_t) * n);
+        }
+    }
+    free(keys);
+    free(sorted);
+    free(sorted_r);
+    int32_t node = -1;
+    if (have) {
+        node = rf_new_node(o);
+        if (node >= 0) {
+            int32_t l = rf_learn_recursive(ds, p, best_ids, best_r, best_pos, fids, nf, depth + 1, o);
+            if (l < 0) l = rf_leaf(o, rf_compute_output(ds, best_ids, best_pos));
+            int32_t r = rf_learn_recursive(ds, p, best_ids + best_pos, best_r + best_pos, n - best_pos, fids, nf, depth + 1, o);
+            if (r < 0) r = rf_leaf(o, rf_compute_output(ds, best_ids + best_pos, n - best_pos));
+            o->fid[node] = (int32_t)best_fid;
+            o->split[node] = best_split;
+            o->lhs[node] = l;
+            o->rhs[node] = r;
+        }
+    }
+    free(best_ids);
+    free(best_r);
+    return node;
+}
+
+static int cmp_str_u32(const void *a, const void *b) {
+    char sa[16], sb[16];
+    snprintf(sa, sizeof sa, "%u", *(const uint32_t *)a);
+    snprintf(sb, sizeof sb, "%u", *(const uint32_t *)b);
+    return strcmp(sa, sb);
+}
+
+/* random_forest.rs:288-342 learn_ensemble.  fids: the dataset's features.  Output: flattened trees (see
+ * oracle_score_ensemble), roots[num_trees], weights[num_trees].  out_sample (optional, [num_trees][2]): number of
+ * features / instances of each tree's sample.  Returns the number of nodes, or -(err) (1 capacity, 2 reference panic). */
+int64_t oracle_rf_learn(const oracle_dataset *ds, const oracle_rf_params *p, int measure, int64_t depth, const double *norms,
+                        const uint32_t *fids, size_t nf, int32_t *out_fid, double *out_split, int32_t *out_lhs,
+                        int32_t *out_rhs, size_t cap, int32_t *out_roots, double *out_weights, uint32_t *out_sample) {
+    rf_out o = {out_fid, out_split, out_lhs, out_rhs, 0, cap, 0};
+    oracle_rand64 rand;
+    oracle_rand64_new(&rand, p->seed);
+    uint64_t *seeds = (uint64_t *)malloc(sizeof(uint64_t) * (p->num_trees ? p->num_trees : 1));
+    for (uint32_t t = 0; t < p->num_trees; t++) seeds[t] = oracle_rand64_u64(&rand);
+    /* sampling.rs:40-45: features ascending, query-id STRINGS ascending */
+    uint32_t *feat_sorted = (uint32_t *)malloc(sizeof(uint32_t) * (nf ? nf : 1));
+    memcpy(feat_sorted, fids, sizeof(uint32_t) * nf);
+    for (size_t i = 1; i < nf; i++) /* insertion sort: nf is small */
+        for (size_t j = i; j > 0 && feat_sorted[j - 1] > feat_sorted[j]; j--) {
+            uint32_t tmp = feat_sorted[j];
+            feat_sorted[j] = feat_sorted[j - 1];
+            feat_sorted[j - 1] = tmp;
+        }
+    uint32_t *q_sorted = (uint32_t *)malloc(sizeof(uint32_t) * (ds->nq ? ds->nq : 1)); /* indices into ds->qid */
+    uint32_t *qid_sorted = (uint32_t *)malloc(sizeof(uint32_t) * (ds->nq ? ds->nq : 1));
+    memcpy(qid_sorted, ds->qid, sizeof(uint32_t) * ds->nq);
+    qsort(qid_sorted, ds->nq, sizeof(uint32_t), cmp_str_u32);
+    const size_t n_features = nf ? ((size_t)((double)nf * p->feature_sampling_rate) > 1 ? (size_t)((double)nf * p->feature_sampling_rate) : 1) : 0;
+    const size_t n_queries = ds->nq ? ((size_t)((double)ds->nq * p->instance_sampling_rate) > 1 ? (size_t)((double)ds->nq * p->instance_sampling_rate) : 1) : 0;
+    uint32_t *fshuf = (uint32_t *)malloc(sizeof(uint32_t) * (nf ? nf : 1));
+    uint32_t *qshuf = (uint32_t *)malloc(sizeof(uint32_t) * (ds->nq ? ds->nq : 1));
+    uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (ds->n ? ds->n : 1));
+    uint32_t *iota = (uint32_t *)malloc(sizeof(uint32_t) * (ds->n ? ds->n : 1));
+    for (size_t i = 0; i < ds->n; i++) iota[i] = (uint32_t)i;
+    double *scores = (double *)malloc(sizeof(double) * (ds->n ? ds->n : 1));
+    double *perq = (double *)malloc(sizeof(double) * (ds->nq ? ds->nq : 1));
+    for (uint32_t t = 0; t < p->num_trees && !o.err; t++) {
+        oracle_rand64 local;
+        oracle_rand64_new(&local, seeds[t]);
+        memcpy(fshuf, feat_sorted, sizeof(uint32_t) * nf);
+        shuffle_u32(fshuf, nf, &local); /* randutil.rs:14-18: shuffle everything, take the first n */
+        memcpy(qshuf, qid_sorted, sizeof(uint32_t) * ds->nq);
+        shuffle_u32(qshuf, ds->nq, &local);
+        size_t n = 0;
+        for (size_t q = 0; q < ds->nq; q++) { /* sampling.rs:56-60, in this dataset's query order */
+            int chosen = 0;
+            for (size_t j = 0; j < n_queries; j++)
+                if (qshuf[j] == ds->qid[q]) {
+                    chosen = 1;
+                    break;
+                }
+            if (!chosen) continue;
+            for (size_t kk = ds->qoff[q]; kk < ds->qoff[q + 1]; kk++) ids[n++] = ds->qdocs[kk];
+        }
+        if (out_sample) {
+            out_sample[2 * t] = (uint32_t)n_features;
+            out_sample[2 * t + 1] = (uint32_t)n;
+        }
+        /* random_forest.rs:344-352 learn_decision_tree */
+        int32_t root = rf_learn_recursive(ds, p, ids, iota, n, fshuf, n_features, 1, &o);
+        if (root < 0 && !o.err) root = rf_leaf(&o, rf_compute_output(ds, ids, n));
+        out_roots[t] = root;
+        out_weights[t] = 1.0;
+        if (p->weight_trees && !o.err) { /* random_forest.rs:315,332-336: the tree's evaluate_mean over the whole dataset */
+            double one = 1.0;
+            oracle_score_ensemble(ds, 1, &root, &one, out_fid, out_split, out_lhs, out_rhs, scores);
+            o.err |= oracle_metric_from_scores(ds, measure, depth, scores, norms, perq, NULL) ? 2 : 0;
+            out_weights[t] = mean_seq(perq, ds->nq);
+        }
+    }
+    (void)q_sorted;
+    free(seeds), free(feat_sorted), free(q_sorted), free(qid_sorted), free(fshuf), free(qshuf), free(ids), free(iota), free(scores), free(perq);
+    return o.err ? -(int64_t)o.err : (int64_t)o.n;
 }

@@ -23,6 +23,23 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+class RFParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("num_trees", C.c_uint32),
+        ("weight_trees", C.c_int32),
+        ("split_method", C.c_int32),
+        ("instance_sampling_rate", C.c_double),
+        ("feature_sampling_rate", C.c_double),
+        ("min_leaf_support", C.c_uint32),
+        ("split_candidates", C.c_uint32),
+        ("max_depth", C.c_uint32),
+    ]
+
+
+SPLIT_METHODS = {"SquaredError": 0, "BinaryGiniImpurity": 1, "InformationGain": 2, "TrueVarianceReduction": 3}
+
+
 class CAParams(C.Structure):
     _fields_ = [
         ("num_restarts", C.c_uint32),
@@ -84,6 +101,8 @@ def lib():
     L.oracle_check_div_identity.argtypes = [C.c_int]
     L.oracle_rand64_stream.argtypes = [u64, sz, vp]
     L.oracle_shuffle_with_seed.argtypes = [u64, vp, sz]
+    L.oracle_rf_learn.restype = i64
+    L.oracle_rf_learn.argtypes = [vp, C.POINTER(RFParams), C.c_int, i64, vp, vp, sz, vp, vp, vp, vp, sz, vp, vp, vp]
     L.oracle_resident_update.restype = None
     L.oracle_resident_update.argtypes = [vp, vp, sz, dbl, dbl, dbl]
     _lib = L
@@ -232,6 +251,45 @@ class Dataset:
         w = np.ascontiguousarray(w, dtype=np.float64)
         norms = np.ascontiguousarray(norms, dtype=np.float64)
         return lib().oracle_evaluate_mean_linear(self.ptr, kind, depth, _p(norms), _p(w), len(w))
+
+    def rf_learn(self, measure: str, params: dict, fids=None, norms=None):
+        """src/random_forest.rs:288-342.  params: the reference's RandomForestParams as a dict (split_method: the
+        variant's name, or the serde form {"SquaredError": []}).  Returns (trees as nested dicts in the reference's
+        JSON shape, weights, per-tree (n_features, n_instances) of the sample)."""
+        kind, depth = parse_measure(measure)
+        if norms is None:
+            norms = self.default_norms(measure)
+        norms = np.ascontiguousarray(norms, dtype=np.float64)
+        if fids is None:
+            fids = np.arange(self.d, dtype=np.uint32)
+        fids = np.ascontiguousarray(fids, dtype=np.uint32)
+        sm = params.get("split_method", "SquaredError")
+        if isinstance(sm, dict):
+            sm = next(iter(sm))
+        p = RFParams(int(params["seed"]), int(params["num_trees"]), int(bool(params.get("weight_trees", False))),
+                     SPLIT_METHODS[sm], float(params["instance_sampling_rate"]), float(params["feature_sampling_rate"]),
+                     int(params["min_leaf_support"]), int(params["split_candidates"]), int(params["max_depth"]))
+        nt = p.num_trees
+        cap = max(16, nt * (2 * self.n + 1))
+        cap = min(cap, nt * (2 ** min(int(p.max_depth), 20) + 1))
+        fid = np.zeros(cap, dtype=np.int32)
+        split = np.zeros(cap, dtype=np.float64)
+        lhs = np.zeros(cap, dtype=np.int32)
+        rhs = np.zeros(cap, dtype=np.int32)
+        roots = np.zeros(max(1, nt), dtype=np.int32)
+        weights = np.zeros(max(1, nt), dtype=np.float64)
+        sample = np.zeros((max(1, nt), 2), dtype=np.uint32)
+        n = lib().oracle_rf_learn(self.ptr, C.byref(p), kind, depth, _p(norms), _p(fids), len(fids), _p(fid), _p(split),
+                                  _p(lhs), _p(rhs), cap, _p(roots), _p(weights), _p(sample))
+        if n < 0:
+            raise RuntimeError("oracle_rf_learn: error %d (1 = node capacity, 2 = the reference would have panicked)" % -n)
+
+        def build(k):
+            if fid[k] < 0:
+                return {"LeafNode": float(split[k])}
+            return {"FeatureSplit": {"fid": int(fid[k]), "split": float(split[k]), "lhs": build(int(lhs[k])), "rhs": build(int(rhs[k]))}}
+
+        return [build(int(r)) for r in roots[:nt]], weights[:nt].copy(), sample[:nt].copy()
 
     def ca_learn(self, measure: str, params: dict, fids=None, threads=1, norms=None,
                  restart_range=None, max_evals_per_restart=0):
