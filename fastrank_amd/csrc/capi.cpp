@@ -10,6 +10,7 @@
 #include "../../include/fastrank.h"
 #include "host.hpp"
 #include "loader.hpp"
+#include "rf_train.hpp"
 
 using fr::FrError;
 using frjson::Value;
@@ -155,6 +156,7 @@ struct ParsedRequest {
     std::string measure;
     bool is_ca = false;
     fr::CAParams ca;
+    fr::RFParams rf;
     bool has_qrel = false;
     fr::QRel qrel;
 };
@@ -173,6 +175,7 @@ ParsedRequest parse_train_request(const std::string& text) {
         rq.ca = fr::CAParams::from_json(var.second);
     } else if (var.first == "RandomForest") {
         rq.is_ca = false;
+        rq.rf = fr::RFParams::from_json(var.second);
     } else {
         fr::fail_raw("Error(\"unknown variant `" + var.first +
                      "`, expected `CoordinateAscent` or `RandomForest`\", line: 1, column: 1)");
@@ -254,6 +257,24 @@ fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     } else {
         m = fr::ca_select(hist, rq.ca.output_ensemble);
     }
+    return m;
+}
+
+// json_api.rs:41-48 -> random_forest::learn_ensemble
+fr::Model train_rf(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq) {
+    auto t0 = std::chrono::steady_clock::now();
+    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+    fr::RFTrainer trainer(view, std::move(ev), rq.rf);
+    fr::Model m = trainer.learn();
+    fr::TrainStats st;
+    st.path = "random_forest";
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    st.restarts = trainer.stats().trees;
+    st.ticks = trainer.stats().levels;
+    st.groups = trainer.stats().batches;
+    st.raw_evals = trainer.stats().candidates;  // split candidates evaluated
+    st.useful_evals = trainer.stats().nodes;    // tree nodes produced
+    g_last_stats = st;
     return m;
 }
 
@@ -480,14 +501,10 @@ const CResult* train_model(void* train_request_json, void* dataset) {
         // result_train_model reports the null dataset first (src/ffi.rs:189-193)
         const CDataset& ds = require_dataset(dataset);
         ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
-        if (!rq.is_ca)
-            fr::fail_str(
-                "RandomForest training is outside the MI355X hot path (SURVEY.md section 8); only tree-ensemble "
-                "*scoring* is implemented. Train with CoordinateAscent or load a forest with model_from_json.");
         std::lock_guard<std::mutex> lk(g_api_mu);
         auto* out = new CModel();
         try {
-            out->actual = train_ca(ds.view, rq, 0, rq.ca.num_restarts, nullptr);
+            out->actual = rq.is_ca ? train_ca(ds.view, rq, 0, rq.ca.num_restarts, nullptr) : train_rf(ds.view, rq);
         } catch (...) {
             delete out;
             throw;

@@ -19,10 +19,16 @@
 //   kernels_sortnet.inc     (generated, tools/gen_sortnet.py) compare-exchange networks over register-resident keys
 //   kernels_fullverify.inc  fullrank_verify_kernel: NDCG of any depth / AP by sorting approximate keys in registers
 //                           and verifying the gaps (the exact kernels of kernels_fullrank.inc redo what fails)
+//   kernels_rf.inc          random-forest TRAINING: level-synchronous split search over a batch of trees (rocPRIM radix sort +
+//                           sequential-association importance kernels)
 //   device_dataset.inc      DeviceDataset: HBM layout (runs, tiles, tables) and every launcher
 #include "device.hpp"
 
 #include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -46,6 +52,7 @@ namespace frdev {
 #include "kernels_rr.inc"
 #include "kernels_sortnet.inc"
 #include "kernels_fullverify.inc"
+#include "kernels_rf.inc"
 #include "device_dataset.inc"
 
 }  // namespace frdev

@@ -166,6 +166,28 @@ class DeviceDataset {
     size_t last_ldm() const;
     bool download_last_matrix(std::vector<double>* out, size_t* ldm, std::string* err);
 
+    // --- random-forest training (src/random_forest.rs:211-408; kernels_rf.inc) ---------------------------------
+    // A batch of trees is grown level by level.  rf_begin: tree t's sampled instances are root_ids[root_off[t] ..
+    // root_off[t+1]) (original instance ids, in the order the sample is iterated), its sampled features
+    // feats[t*nf .. t*nf+nf); every instance starts in node key t.
+    struct RfActive { uint32_t tree, key, n; };
+    struct RfCand { double position, importance; uint32_t ids_i, flags, pos_l, pos_r; };
+    struct RfSplit { int32_t fslot; uint32_t pos, left, right; };
+    bool rf_begin(const std::vector<uint32_t>& root_off, const std::vector<uint32_t>& root_ids, uint32_t nf,
+                  const std::vector<uint32_t>& feats, std::string* err);
+    // compute_output of every tree's whole sample (random_forest.rs:344-351: a root that does not split)
+    bool rf_root_outputs(std::vector<double>* out, std::string* err);
+    // one level: for every active node (slot = its index in `active`; slot_of_key maps node keys to slots, IDX for
+    // closed nodes) and every feature slot, the k-1 split candidates: cands[(slot*nf + fi)*(k-1) + c-1];
+    // label_minmax[slot*2 .. +2)
+    bool rf_level(const std::vector<RfActive>& active, const std::vector<uint32_t>& slot_of_key, uint32_t k, int method,
+                  uint32_t min_leaf, std::vector<RfCand>* cands, std::vector<float>* label_minmax, std::string* err);
+    // the host's decisions for the level just evaluated: instances move to the children's keys; child_out[slot*2 + side]
+    // = compute_output of that child (random_forest.rs:32-41)
+    bool rf_split(const std::vector<RfSplit>& splits, std::vector<double>* child_out, std::string* err);
+    void rf_end();
+    size_t rf_bytes_per_item() const { return 32; }  // device bytes per (sampled instance x sampled feature) of a batch
+
     int take_flags();  // returns and clears the accumulated kernel error bits
 
   private:

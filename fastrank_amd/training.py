@@ -57,8 +57,10 @@ class CoordinateAscentParams(_LearnerParams):
 
 @dataclasses.dataclass
 class RandomForestParams(_LearnerParams):
-    """src/random_forest.rs:127-157.  Forest *training* is outside the MI355X hot path (the library
-    answers with an error); the class exists so that requests round-trip and forests can be scored."""
+    """src/random_forest.rs:127-157; trained on the device (csrc/rf_train.hpp, kernels_rf.inc).  As in the reference
+    (fastrank/training.py:36-60) the dataclass default of `split_method` is a bare string, which the request parser --
+    serde there, its restatement here -- rejects: requests made by `TrainRequest.random_forest()` carry the wire
+    form {"SquaredError": []} (one of SquaredError, BinaryGiniImpurity, InformationGain, TrueVarianceReduction)."""
 
     VARIANT: ClassVar[str] = "RandomForest"
 

@@ -182,8 +182,15 @@ def test_bad_measure_and_unsupported_training_are_errors(trec):
         ds.evaluate(m, "p@5")
     with pytest.raises(Exception, match="Couldn't parse after the @"):
         ds.evaluate(m, "ndcg@x")
-    with pytest.raises(Exception, match="RandomForest training is outside"):
-        ds.train_model(fr.TrainRequest.random_forest())
+    # the request's split_method must be serde's tuple-variant form (src/random_forest.rs:14-20): a bare string (the
+    # Python dataclass default, as in the reference's fastrank/training.py:42) does not deserialize there either
+    bad = fr.TrainRequest.random_forest()
+    bad.params.split_method = "SquaredError"
+    with pytest.raises(Exception, match="expected tuple variant"):
+        ds.train_model(bad)
+    bad.params.split_method = {"Entropy": []}
+    with pytest.raises(Exception, match="unknown variant `Entropy`"):
+        ds.train_model(bad)
 
 
 @pytest.mark.skipif(native.device_count() > 0, reason="checks the no-GPU failure mode")
@@ -191,7 +198,8 @@ def test_compute_without_gpu_fails_loudly(trec):
     ds = fr.CDataset.from_numpy(trec["train_X"], trec["train_y"], trec["train_qid"])
     m = fr.CModel.from_dict({"Linear": {"weights": [1.0] * 6}})
     for call in (lambda: ds.evaluate(m, "ndcg@5"), lambda: m.predict_scores(ds),
-                 lambda: ds.train_model(fr.TrainRequest.coordinate_ascent())):
+                 lambda: ds.train_model(fr.TrainRequest.coordinate_ascent()),
+                 lambda: ds.train_model(fr.TrainRequest.random_forest())):
         with pytest.raises(Exception, match="no MI355X/HIP device"):
             call()
 
