@@ -190,17 +190,14 @@ class RFTrainer {
         const uint32_t T = t1 - t0;
         std::string err;
         if (!dev.rf_begin(root_off, root_ids, nf, feats, &err)) fail_str(err);
-        std::vector<double> root_out;
-        if (!dev.rf_root_outputs(&root_out, &err)) fail_str(err);
         std::vector<std::shared_ptr<TreeNode>> roots(T);
         std::vector<Open> open;
         uint32_t next_key = T;  // keys 0..T-1 are the roots
         for (uint32_t t = 0; t < T; t++) {
             roots[t] = std::make_shared<TreeNode>();
             roots[t]->leaf = true;
-            roots[t]->value = root_out[t];  // random_forest.rs:348-351: Err(_) -> LeafNode(to_output(dataset))
             const uint32_t n = root_off[t + 1] - root_off[t];
-            if (enterable(n, 1)) open.push_back({t, t, n, roots[t].get(), root_out[t], 1});
+            if (enterable(n, 1)) open.push_back({t, t, n, roots[t].get(), 0.0, 1});
         }
         const uint32_t k = p_.split_candidates;
         while (!open.empty()) {
@@ -288,6 +285,18 @@ class RFTrainer {
                 }
             }
             open.swap(next);
+        }
+        {
+            // random_forest.rs:348-351: a root that did not split is LeafNode(to_output(dataset)) -- rare, so the sequential
+            // mean over the whole sample is only computed when some tree needs it
+            bool need = false;
+            for (uint32_t t = 0; t < T; t++) need = need || roots[t]->leaf;
+            if (need) {
+                std::vector<double> root_out;
+                if (!dev.rf_root_outputs(&root_out, &err)) fail_str(err);
+                for (uint32_t t = 0; t < T; t++)
+                    if (roots[t]->leaf) roots[t]->value = root_out[t];
+            }
         }
         for (uint32_t t = 0; t < T; t++) {
             Model& mm = out.members[t0 + t];
