@@ -31,6 +31,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

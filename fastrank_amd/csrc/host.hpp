@@ -367,6 +367,7 @@ struct DatasetView {
     void build_csr() {
         if (csr_built) return;
         const DataCore& c = *core;
+        const auto t_csr0 = std::chrono::steady_clock::now();
         for (uint32_t id : instances)  // (the reference panics on a NaN label: src/dense_dataset.rs:114-123)
             if (c.gain[id] != c.gain[id]) fail_str("NaN in ys[" + std::to_string(id) + "]");
         // queries in first-appearance order over this view's instances (counting pass, then fill)
@@ -412,6 +413,9 @@ struct DatasetView {
         csr.gain.resize(csr.n);
         for (size_t p = 0; p < csr.n; p++) csr.gain[p] = c.gain[csr.perm[p]];
         csr_built = true;
+        if (getenv("FR_UPLOAD_TIMING"))
+            fprintf(stderr, "[upload] %-28s %7.1f ms\n", "build_csr (group, sort)",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_csr0).count());
     }
 
     frdev::DeviceDataset& device() {
