@@ -83,6 +83,7 @@ def _load():
         "fr_rank_order": (vp, [vp, vp, vp, sz, vp, sz]),
         "fr_dataset_num_queries": (sz, [vp]),
         "fr_dataset_num_instances": (sz, [vp]),
+        "fr_dataset_device_info": (vp, [vp]),
         "fr_evaluate_candidates": (vp, [vp, vp, C.c_char_p, sz, vp, vp, vp, vp, vp, vp]),
         "fr_profile_enable": (None, [C.c_int]),
         "fr_profile_reset": (None, []),

@@ -381,6 +381,7 @@ const CResult* dataset_query_sampling(CDataset* dataset, const void* queries_jso
         child->core = ds.view->core;
         child->features = ds.view->features;
         child->sampled = true;
+        child->parent = ds.view;
         for (auto& qi : instances_by_query(*ds.view))
             if (wanted.count(qi.first)) child->instances.insert(child->instances.end(), qi.second.begin(), qi.second.end());
         auto* out = new CDataset();
@@ -417,6 +418,8 @@ const CResult* dataset_feature_sampling(CDataset* dataset, const void* feature_j
         child->features.assign(keep.begin(), keep.end());
         child->instances = ds.view->instances;
         child->sampled = true;
+        child->parent = ds.view;
+        child->same_instances_as_parent = true;
         auto* out = new CDataset();
         out->view = child;
         return out;
@@ -848,6 +851,24 @@ size_t fr_dataset_num_queries(const CDataset* dataset) {
     } catch (...) {
         return SIZE_MAX;
     }
+}
+
+const void* fr_dataset_device_info(const CDataset* dataset) {
+    return json_call([&]() {
+        const CDataset& ds = require_dataset(dataset);
+        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::shared_ptr<frdev::DeviceDataset> devp = ds.view->device_ptr();
+        frdev::DeviceDataset& dev = *devp;
+        fr::DatasetView* owner = ds.view->matrix_owner(nullptr);
+        const bool is_parents = owner != ds.view.get() && owner->device_ptr() == devp;  // a feature sample: the parent's object itself
+        Value o = Value::object();
+        o.set("hbm_bytes_owned", Value::uint(is_parents ? 0 : dev.hbm_bytes()));
+        o.set("shares_parent_matrix", Value::boolean(is_parents || dev.shares_parent_matrix()));
+        o.set("is_parent_device_dataset", Value::boolean(is_parents));
+        o.set("queries", Value::uint(dev.nq()));
+        o.set("instances", Value::uint(dev.n()));
+        return frjson::dump(o);
+    });
 }
 
 size_t fr_dataset_num_instances(const CDataset* dataset) {

@@ -87,6 +87,13 @@ struct KernelStat {
 class DeviceDataset {
   public:
     static std::shared_ptr<DeviceDataset> create(const HostCSR& csr, std::string* err);
+    // A view of `parent` restricted to some of its queries (src/sampling.rs:117-133 with_queries): shares the parent's
+    // feature tiles and per-document arrays in HBM (no second copy of X) and only builds its own query / run tables.
+    // csr = the view's own CSR (same documents per query, same order inside a query as the parent);
+    // parent_query[q] = index of the view's query q in the parent.
+    static std::shared_ptr<DeviceDataset> create_view(const std::shared_ptr<DeviceDataset>& parent, const HostCSR& csr,
+                                                      const std::vector<uint32_t>& parent_query, std::string* err);
+    bool shares_parent_matrix() const;
     ~DeviceDataset();
 
     size_t n() const;

@@ -354,6 +354,11 @@ struct DatasetView {
     std::vector<uint32_t> features;   // feature ids visible to trainers
     std::vector<uint32_t> instances;  // instance ids of this view, iteration order
     bool sampled = false;
+    // The view this one was sampled from (dataset_query_sampling / dataset_feature_sampling).  On the device a sampled
+    // view does not get a matrix of its own: a feature sample uses its parent's DeviceDataset as it is (feature lists
+    // only steer the trainers), a query sample gets query / run tables over the parent's tiles (DeviceDataset::create_view).
+    std::shared_ptr<DatasetView> parent;
+    bool same_instances_as_parent = false;
 
     // lazily built device form
     std::mutex mu;
@@ -418,17 +423,49 @@ struct DatasetView {
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_csr0).count());
     }
 
-    frdev::DeviceDataset& device() {
+    // the view that owns the device matrix this one's data lives in, and whether this view covers all of its instances
+    DatasetView* matrix_owner(bool* all_instances) {
+        DatasetView* v = this;
+        bool all = true;
+        while (v->parent) {
+            all = all && v->same_instances_as_parent;
+            v = v->parent.get();
+        }
+        if (all_instances) *all_instances = all;
+        return v;
+    }
+    std::shared_ptr<frdev::DeviceDataset> device_ptr() {
         std::lock_guard<std::mutex> lk(mu);
-        if (dev) return *dev;
+        if (dev) return dev;
         build_csr();
         for (size_t p = 0; p < csr.n; p++)
             if (csr.gain[p] != csr.gain[p]) fail_str("NaN in ys[" + std::to_string(csr.perm[p]) + "]");
         std::string err;
+        bool all = true;
+        DatasetView* owner = matrix_owner(&all);
+        if (owner != this && !getenv("FR_VIEW_COPIES")) {  // (FR_VIEW_COPIES=1: every view tiles its own matrix, as in round 1)
+            std::shared_ptr<frdev::DeviceDataset> pdev = owner->device_ptr();
+            if (all) {
+                dev = pdev;  // same documents: the parent's device dataset as it is
+            } else {
+                // queries of this view -> queries of the owner, through the core's query index
+                std::vector<int32_t> owner_q(core->qnames.size(), -1);
+                for (size_t q = 0; q < owner->csr_query.size(); q++) owner_q[owner->csr_query[q]] = (int32_t)q;
+                std::vector<uint32_t> pq(csr.nq);
+                for (size_t q = 0; q < csr.nq; q++) {
+                    if (owner_q[csr_query[q]] < 0) fail_str("sampled view: query not in the dataset it was sampled from");
+                    pq[q] = (uint32_t)owner_q[csr_query[q]];
+                }
+                dev = frdev::DeviceDataset::create_view(pdev, csr, pq, &err);
+                if (!dev) fail_str(err);
+            }
+            return dev;
+        }
         dev = frdev::DeviceDataset::create(csr, &err);
         if (!dev) fail_str(err);
-        return *dev;
+        return dev;
     }
+    frdev::DeviceDataset& device() { return *device_ptr(); }
     const frdev::HostCSR& host_csr() {
         std::lock_guard<std::mutex> lk(mu);
         build_csr();

@@ -35,6 +35,11 @@ def num_queries(dataset: CDataset) -> int:
     return nq
 
 
+def device_info(dataset: CDataset) -> Dict:
+    """How the dataset lives on the device (builds the device form if needed); see include/fastrank.h."""
+    return _json_reply(_load().fr_dataset_device_info(dataset.pointer))
+
+
 def predict_scores_dense(model: CModel, dataset: CDataset, n_total: Optional[int] = None) -> np.ndarray:
     """Scores indexed by instance id (NaN where the id is not part of a sampled dataset)."""
     n = int(n_total if n_total is not None else _load().fr_dataset_num_instances(dataset.pointer))

@@ -161,6 +161,12 @@ const void *fr_evaluate_dense(const CModel *model, const CDataset *dataset, cons
  * out_instance_ids[n] grouped by query (device query order), best first; out_offsets[nq+1]. */
 const void *fr_rank_order(const CModel *model, const CDataset *dataset, uint32_t *out_instance_ids,
                           size_t n, uint64_t *out_offsets, size_t nq_plus_1);
+/* JSON about the dataset's device form (built on first use): {"hbm_bytes_owned","shares_parent_matrix",
+ * "is_parent_device_dataset","queries","instances"}.  A view made by dataset_query_sampling /
+ * dataset_feature_sampling does not tile a second copy of X: a feature sample uses its parent's device dataset as it is,
+ * a query sample owns only query / run tables over the parent's tiles (src/dataset.rs:101-178 keeps views as id lists
+ * over the parent for the same reason). */
+const void *fr_dataset_device_info(const CDataset *dataset);
 /* Number of queries / instances in the dataset view. */
 size_t fr_dataset_num_queries(const CDataset *dataset);
 size_t fr_dataset_num_instances(const CDataset *dataset);

@@ -1165,3 +1165,81 @@ def test_randomised_parity_soak():
     last = out.stdout.strip().splitlines()[-1]
     assert out.returncode == 0, out.stdout[-2000:]
     assert json.loads(last)["mismatches"] == 0
+
+
+def test_sampled_views_share_the_parents_matrix_and_match_the_oracle(monkeypatch):
+    """dataset_query_sampling / dataset_feature_sampling views do not tile a second copy of X:
+    a query sample owns only query / run tables over the parent's tiles -- its runs start wherever its first query
+    starts inside a tile -- and a feature sample IS its parent's device dataset.  Every path (fused NDCG@k training on
+    resident sums, sort-and-verify, MRR, per-query evaluation, tree scoring, rank order, RF training) must give the
+    oracle's numbers for the subset, and the same bits as a view that tiles its own copy (FR_VIEW_COPIES=1)."""
+    X, y, qid = synth_dataset(401, 9000, 24, 120, max_len=200)
+    parent = fr.CDataset.from_numpy(X, y, qid)
+    names = [str(int(v)) for v in dict.fromkeys(qid.tolist())]  # first-appearance order
+    rng = np.random.default_rng(5)
+    chosen = sorted(rng.choice(len(names), size=70, replace=False).tolist())  # gaps of every length between kept queries
+    sub_names = [names[i] for i in chosen]
+    rows = np.isin(np.array([str(int(q)) for q in qid]), sub_names)
+    Xs, ys, qs = np.ascontiguousarray(X[rows]), np.ascontiguousarray(y[rows]), np.ascontiguousarray(qid[rows])
+    c = o.Dataset(Xs, ys, qs)
+    sub = parent.subsample_queries(sub_names)
+    info = native.device_info(sub)
+    pinfo = native.device_info(parent)
+    assert info["shares_parent_matrix"] and not info["is_parent_device_dataset"]
+    assert info["hbm_bytes_owned"] < pinfo["hbm_bytes_owned"] / 20, (info, pinfo)
+    assert info["queries"] == 70 and info["instances"] == int(rows.sum())
+    fsub = sub.subsample_feature_names([str(j) for j in range(0, 24, 2)])
+    finfo = native.device_info(fsub)
+    assert finfo["shares_parent_matrix"] and finfo["hbm_bytes_owned"] < pinfo["hbm_bytes_owned"] / 20
+    fpar = parent.subsample_feature_names([str(j) for j in range(0, 24, 2)])
+    assert native.device_info(fpar)["is_parent_device_dataset"]
+
+    def run_all(view):
+        out = {}
+        for measure in ("ndcg@10", "ndcg", "mrr", "map"):
+            req = fr.TrainRequest.coordinate_ascent()
+            req.measure = measure
+            p = req.params
+            p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 41, True, 3, 4
+            shard = native.train_model_shard(view, req, 0, 3)
+            out[measure] = ([(r["score"], r["weights"]) for r in shard["restarts"]], shard["stats"]["path"], p.to_dict())
+        w = np.linspace(-1, 1, 24)
+        m = fr.CModel.from_dict({"Linear": {"weights": w.tolist()}})
+        out["eval"] = {k: native.evaluate_dense(m, view, k)[1].tolist() for k in ("ndcg@5", "map", "mrr", "ndcg")}
+        out["rank"] = [a.tolist() for a in native.rank_order(m, view)]
+        out["scores"] = native.predict_scores_dense(m, view, len(y)).tolist()
+        rf = fr.TrainRequest.random_forest()
+        rf.measure = "ndcg@5"
+        rf.params.quiet, rf.params.num_trees, rf.params.seed = True, 5, 3
+        out["rf"] = view.train_model(rf).to_dict()
+        out["rf_params"] = rf.params.to_dict()
+        return out
+
+    got = run_all(sub)
+    # oracle on the materialised subset
+    for measure in ("ndcg@10", "ndcg", "mrr", "map"):
+        restarts, path, params = got[measure]
+        exp_s, exp_w, _, err = c.ca_learn(measure, params, threads=2)
+        assert err == 0 and path in ("fused_linesearch", "fused_fullrank")
+        for r, (s, w) in enumerate(restarts):
+            assert s == exp_s[r] and w == exp_w[r].tolist(), measure
+    w = np.linspace(-1, 1, 24)
+    for k, vals in got["eval"].items():
+        exp, _ = c.metric_from_scores(k, c.score_linear(w))
+        assert vals == exp.tolist(), k
+    exp_scores = np.full(len(y), np.nan)
+    exp_scores[rows] = c.score_linear(w)
+    assert np.array_equal(np.asarray(got["scores"]), exp_scores, equal_nan=True)
+    trees, tw, _ = c.rf_learn("ndcg@5", got["rf_params"])
+    # (instance ids differ between the view and the materialised subset, but their ORDER is the same: same forest)
+    assert got["rf"] == {"Ensemble": {"weights": tw.tolist(), "models": [{"DecisionTree": t} for t in trees]}}
+    # and bit for bit what a view with its own copy of the matrix gives
+    monkeypatch.setenv("FR_VIEW_COPIES", "1")
+    own = parent.subsample_queries(sub_names)
+    assert not native.device_info(own)["shares_parent_matrix"]
+    ref = run_all(own)
+    for k in ("ndcg@10", "ndcg", "mrr", "map", "eval", "rank", "scores", "rf"):
+        if k == "scores":
+            assert np.array_equal(np.asarray(got[k]), np.asarray(ref[k]), equal_nan=True)
+        else:
+            assert got[k] == ref[k], k
