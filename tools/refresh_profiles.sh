@@ -54,6 +54,11 @@ for steal in 0 4; do
   FR_BENCH_DEVICE=0 FR_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 2 --steps 10 --warmup 2 --shape 10k --restarts-total 32 --steal-block $steal 2> "$OUT/bench_2rank_$steal.err" | tail -1 > "$OUT/${TAG}_bench_2rank_1gpu_steal$steal.json"
 done
+# random-forest training and sampled views
+python tools/rfbench.py --shape 30k --trees 100 --cpu-trees 1 --check 2>&1 | tail -1 > "$OUT/${TAG}_rfbench_30k.json"
+python tools/rfbench.py --shape 10k --trees 30 --split-candidates 32 --cpu-trees 1 --check 2>&1 | tail -1 > "$OUT/${TAG}_rfbench_10k_k32.json"
+python tools/viewbench.py 2>&1 | tail -1 > "$OUT/${TAG}_views_30k.json"
+FR_UPLOAD_TIMING=1 python tools/train_e2e.py --shape 30k --restarts 32 --max-ticks 3 2>&1 | grep "upload\]" > "$OUT/${TAG}_upload_stages.txt"
 python tools/train_e2e.py 2>&1 | tail -1 > "$OUT/${TAG}_train_e2e_10k.json"
 python tools/train_e2e.py --measure mrr --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1 > "$OUT/${TAG}_train_mrr_30k.json"
 { python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; FR_LS_EXACT=1 python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; } > "$OUT/${TAG}_train_e2e_30k.json"
