@@ -46,7 +46,7 @@ N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
 # sources whose SHA-1 the PMC figures of profiles/hbm_traffic.json are tied to (tools/pmc_bench.sh records them)
 PMC_SOURCES = ("kernels_verify.inc", "kernels_linesearch.inc", "device_dataset.inc", "host.hpp")
-DATA_KINDS = ("mslr", "ties", "hard")
+DATA_KINDS = ("mslr", "ties", "tiesmix", "hard")
 
 
 def gen_mslr_shaped(seed, n, d, q, kind="mslr"):
@@ -56,7 +56,9 @@ def gen_mslr_shaped(seed, n, d, q, kind="mslr"):
     documents keep entering the top-k lists).  kind="ties": every column floor()-quantised (small
     integers, like most MSLR columns) and 20 % of each query's documents are exact duplicates
     (features and label) of another document of the query -- score ties the reference resolves
-    by its gain/id tie-break, i.e. pairs the bound-and-verify kernels must hand to the exact ones."""
+    by its gain/id tie-break only when their gains differ.  kind="tiesmix": like "ties", but a quarter of the duplicates
+    keep their OWN label: exact score ties between different gains, which only the reference's tie-break (gain asc, id asc)
+    orders -- those (query, group) pairs must be recomputed by the exact kernels."""
     rng = np.random.default_rng(seed)
     lens = np.clip(rng.lognormal(np.log(100.0), 0.6, q), 1, 1300)
     lens = np.maximum(1, np.floor(lens * (n / lens.sum()))).astype(np.int64)
@@ -90,17 +92,20 @@ def gen_mslr_shaped(seed, n, d, q, kind="mslr"):
             col = np.where(rng.random(n) < 0.7, 0.0, rng.random(n))
         if j in signal:
             col = col + coef * y
-        if kind == "ties":
+        if kind in ("ties", "tiesmix"):
             col = np.floor(col * 4.0)
         XT[j] = col.astype(np.float32)
     X = np.ascontiguousarray(XT.T)
     del XT
-    if kind == "ties":
+    if kind in ("ties", "tiesmix"):
         starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
         dup = np.nonzero(rng.random(n) < 0.2)[0]
         qi = np.searchsorted(starts, dup, side="right") - 1
         src = starts[qi] + np.floor(rng.random(len(dup)) * lens[qi]).astype(np.int64)
         Xs, ys = X[src].copy(), y[src].copy()
+        if kind == "tiesmix":
+            keep = rng.random(len(dup)) < 0.25
+            ys = np.where(keep, y[dup], ys)
         X[dup], y[dup] = Xs, ys
     return X, y, qid
 

@@ -1,0 +1,52 @@
+"""Host-side pieces of bench.py that need no GPU: the synthetic data kinds and the bookkeeping that ties the static PMC
+figures to the sources they were captured on."""
+import json
+import os
+
+import numpy as np
+
+import bench
+
+
+def test_data_kinds_have_the_documented_structure():
+    n, d, q = 20000, 24, 150
+    base = bench.gen_mslr_shaped(3, n, d, q)
+    assert base[0].shape == (n, d) and base[0].dtype == np.float32 and len(np.unique(base[2])) == q
+    hard = bench.gen_mslr_shaped(3, n, d, q, "hard")
+    assert np.array_equal(hard[1], base[1]) and not np.array_equal(hard[0][:, 0], base[0][:, 0])  # weaker label signal
+    for kind in ("ties", "tiesmix"):
+        X, y, qid = bench.gen_mslr_shaped(3, n, d, q, kind)
+        assert (X == np.floor(X)).all(), "every column quantised"
+        # duplicated feature rows inside a query, and (tiesmix only) some of them with different labels
+        dup_same = dup_diff = 0
+        for qq in np.unique(qid)[:40]:
+            rows = np.nonzero(qid == qq)[0]
+            seen = {}
+            for i in rows:
+                key = X[i].tobytes()
+                if key in seen:
+                    if y[seen[key]] == y[i]:
+                        dup_same += 1
+                    else:
+                        dup_diff += 1
+                seen.setdefault(key, i)
+        assert dup_same > 50
+        assert (dup_diff == 0) if kind == "ties" else (dup_diff > 10)
+
+
+def test_pmc_constants_carry_the_hash_of_their_sources(tmp_path, monkeypatch):
+    cur = bench.source_sha1()
+    assert set(cur) == set(bench.PMC_SOURCES) and all(v and len(v) == 40 for v in cur.values())
+    tj, meta = bench.load_pmc("30k", usable=False)
+    assert tj == {} and meta["stale"] is None
+    tj, meta = bench.load_pmc("30k", usable=True)
+    committed = json.load(open(os.path.join(bench.ROOT, "profiles", "hbm_traffic.json")))["30k"].get("captured", {})
+    assert meta["current_sha1"] == cur and meta["captured_sha1"] == committed.get("sha1")
+    assert meta["stale"] == (committed.get("sha1") != cur)
+    # a capture without hashes (round 1's file) counts as stale
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "fastrank_amd" / "csrc")
+    (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps({"30k": {"bench_timed_bytes_per_group": 1.0}}))
+    tj, meta = bench.load_pmc("30k", usable=True)
+    assert meta["stale"] is True and tj["bench_timed_bytes_per_group"] == 1.0

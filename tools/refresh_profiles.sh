@@ -46,7 +46,7 @@ cp "$OUT"/kt_tree/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv" 2>/dev/n
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_full" -o p -- python tools/train_e2e.py --measure ndcg --shape 30k --restarts 32 --max-ticks 136 > "$OUT/kt_full.log" 2>&1
 cp "$OUT"/kt_full/*kernel_stats.csv "$OUT/${TAG}_fullrank_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt_full/*/*kernel_stats.csv "$OUT/${TAG}_fullrank_kernel_stats.csv"
 # side measurements on tie-heavy and on hard data: bench line + a whole run each
-for kind in ties hard; do
+for kind in ties tiesmix hard; do
   python bench.py --steps 20 --warmup 3 --data $kind --no-cpu-baseline 2> "$OUT/bench_$kind.err" | tail -1 > "$OUT/${TAG}_bench_$kind.json"
 done
 # the N>1 path on one GPU (gloo, both ranks on device 0): strong scaling of a 32-restart job, static and work stealing
