@@ -767,6 +767,7 @@ def test_redo_list_longer_than_the_first_exact_launch(monkeypatch):
     the device); the rest of a longer list is recomputed after the results came back.  Every query here has
     duplicated documents on top, so every (query, group) pair of 700 queries x 3 groups is on the list."""
     monkeypatch.setenv("FR_REDO_GRID", "512")
+    monkeypatch.setenv("FR_NO_DUP_GROUPS", "1")  # (duplicate groups would let the verify kernel keep these pairs)
     rng = np.random.default_rng(5)
     nq, per = 700, 14
     X = rng.random((nq * per, 6)).astype(np.float32)
@@ -900,6 +901,57 @@ def test_verify_kernel_accepts_ties_inside_one_gain_class(monkeypatch):
         assert fracs["1"][0] > fracs["2"][0] > fracs["3"][0] > 0.0, fracs
         assert fracs["3"][0] < 0.2, fracs
         assert fracs[""][0] < fracs["1"][0] and fracs[""][1] <= fracs["1"][1], fracs  # adaptive: raised after the first line searches
+
+
+def test_verify_kernel_orders_exact_duplicates_by_the_tie_break(monkeypatch):
+    """Documents of a query with bit-identical feature rows score exactly alike under every weight vector, so the
+    reference orders them by its tie-break (gain ascending).  Their duplicate-group id rides in the keys next to the
+    gain class, the class ids descend with the gain, and the verify kernel then KEEPS a close pair of one group even
+    when the gains differ (positive keys; kernels_verify.inc).  Same trajectory as the oracle, far fewer pairs redone
+    than without the groups (FR_NO_DUP_GROUPS=1, where every such pair goes to the exact kernel)."""
+    rng = np.random.default_rng(97)
+    X, y, qid = synth_dataset(97, 9000, 12, 90, max_len=200)
+    X = np.abs(X)
+    for i in np.nonzero(rng.random(len(y)) < 0.15)[0]:
+        if i > 0 and qid[i - 1] == qid[i]:
+            X[i] = X[i - 1]            # same features, its own label: a tie between gain classes
+    c = o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations, p.init_random = 43, True, 4, 5, False  # (uniform start: positive weights)
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+    assert err == 0
+    fracs = {}
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("FR_NO_DUP_GROUPS", off)
+        g = fr.CDataset.from_numpy(X, y, qid)
+        shard, st = _train_stats(g, req)
+        for r in shard["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), off
+        assert st["useful_evals"] == int(exp_e.sum())
+        fracs[off] = (st["verify_redone"] / max(1, st["verify_pairs"]), st["exact_ticks"], st["line_searches"])
+    print("redo fraction / exact-only line searches / line searches with and without duplicate groups:", fracs)
+    if _verify_path_on(resident_needed=True):
+        assert fracs[""][0] < 0.5 * fracs["1"][0] or fracs[""][1] < fracs["1"][1], fracs
+    # random-sign weights (negative keys: the groups are not used there) and per-query values of single candidates
+    monkeypatch.delenv("FR_NO_DUP_GROUPS", raising=False)
+    g = fr.CDataset.from_numpy(X, y, qid)
+    p.init_random, p.seed = True, 44
+    shard, st = _train_stats(g, req)
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    for sign in (1.0, -1.0):
+        bases = np.full((1, 12), sign / 12.0)
+        cands = [np.asarray([sign / 12.0, 0.0, sign * 0.5, -sign * 0.25])]
+        means, pq = native.evaluate_candidates(g, "ndcg@10", [3], bases, cands, per_query=True)
+        for ci in range(4):
+            w = bases[0].copy()
+            w[3] = cands[0][ci]
+            exp, _ = c.metric_from_scores("ndcg@10", c.score_linear(w))
+            assert np.array_equal(pq[:, ci], exp), (sign, ci)
 
 
 def test_mrr_verify_ignores_ties_among_relevant_documents():
