@@ -923,6 +923,7 @@ def test_verify_kernel_orders_exact_duplicates_by_the_tie_break(monkeypatch):
     exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
     assert err == 0
     fracs = {}
+    preset_off = bool(os.environ.get("FR_NO_DUP_GROUPS"))  # (the suite is also run with the groups switched off: parity only)
     for off in ("", "1"):
         if off:
             monkeypatch.setenv("FR_NO_DUP_GROUPS", off)
@@ -933,7 +934,7 @@ def test_verify_kernel_orders_exact_duplicates_by_the_tie_break(monkeypatch):
         assert st["useful_evals"] == int(exp_e.sum())
         fracs[off] = (st["verify_redone"] / max(1, st["verify_pairs"]), st["exact_ticks"], st["line_searches"])
     print("redo fraction / exact-only line searches / line searches with and without duplicate groups:", fracs)
-    if _verify_path_on(resident_needed=True):
+    if _verify_path_on(resident_needed=True) and not preset_off:
         assert fracs[""][0] < 0.5 * fracs["1"][0] or fracs[""][1] < fracs["1"][1], fracs
     # random-sign weights (negative keys: the groups are not used there) and per-query values of single candidates
     monkeypatch.delenv("FR_NO_DUP_GROUPS", raising=False)
@@ -1237,14 +1238,15 @@ def test_sampled_views_share_the_parents_matrix_and_match_the_oracle(monkeypatch
     sub = parent.subsample_queries(sub_names)
     info = native.device_info(sub)
     pinfo = native.device_info(parent)
-    assert info["shares_parent_matrix"] and not info["is_parent_device_dataset"]
-    assert info["hbm_bytes_owned"] < pinfo["hbm_bytes_owned"] / 20, (info, pinfo)
     assert info["queries"] == 70 and info["instances"] == int(rows.sum())
     fsub = sub.subsample_feature_names([str(j) for j in range(0, 24, 2)])
-    finfo = native.device_info(fsub)
-    assert finfo["shares_parent_matrix"] and finfo["hbm_bytes_owned"] < pinfo["hbm_bytes_owned"] / 20
-    fpar = parent.subsample_feature_names([str(j) for j in range(0, 24, 2)])
-    assert native.device_info(fpar)["is_parent_device_dataset"]
+    if not os.environ.get("FR_VIEW_COPIES"):  # (the suite is also run with every view tiling its own copy: parity only)
+        assert info["shares_parent_matrix"] and not info["is_parent_device_dataset"]
+        assert info["hbm_bytes_owned"] < pinfo["hbm_bytes_owned"] / 20, (info, pinfo)
+        finfo = native.device_info(fsub)
+        assert finfo["shares_parent_matrix"] and finfo["hbm_bytes_owned"] < pinfo["hbm_bytes_owned"] / 20
+        fpar = parent.subsample_feature_names([str(j) for j in range(0, 24, 2)])
+        assert native.device_info(fpar)["is_parent_device_dataset"]
 
     def run_all(view):
         out = {}
