@@ -10,6 +10,7 @@
 //   * a tree's sampled instances are iterated query by query in the dataset's query order, instance ids ascending;
 //   * equal feature values sort by that index; equal importances: the last candidate wins.
 #pragma once
+#include <chrono>
 #include <cmath>
 
 #include "host.hpp"
@@ -69,6 +70,7 @@ struct RFParams {  // src/random_forest.rs:127-157
 };
 
 struct RFStats {
+    double t_sample = 0, t_begin = 0, t_level = 0, t_select = 0, t_split = 0, t_weights = 0;  // host wall seconds per stage (FR_RF_TIMING)
     uint32_t trees = 0, batches = 0, levels = 0;
     uint64_t nodes = 0, candidates = 0, sorted_items = 0;
     double seconds = 0.0;
@@ -130,6 +132,7 @@ class RFTrainer {
         if (const char* e = getenv("FR_RF_BATCH_BYTES")) budget = std::max<size_t>(1 << 20, (size_t)atoll(e));
         uint32_t t0 = 0;
         while (t0 < p_.num_trees) {
+            const auto ts0 = std::chrono::steady_clock::now();
             std::vector<uint32_t> root_off(1, 0), root_ids, feats;
             uint32_t t1 = t0;
             while (t1 < p_.num_trees) {
@@ -161,11 +164,15 @@ class RFTrainer {
                 root_off.push_back((uint32_t)root_ids.size());
                 t1++;
             }
+            stats_.t_sample += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
             grow_batch(dev, t0, t1, root_off, root_ids, (uint32_t)n_features, feats, out);
             stats_.batches++;
             t0 = t1;
         }
         dev.rf_end();
+        if (getenv("FR_RF_TIMING"))
+            fprintf(stderr, "[rf] sample %.2f s, begin %.2f s, levels %.2f s, select %.2f s, split %.2f s, weights %.2f s\n", stats_.t_sample,
+                    stats_.t_begin, stats_.t_level, stats_.t_select, stats_.t_split, stats_.t_weights);
         if (!p_.quiet) printf("-----------------------\n");
         stats_.trees = p_.num_trees;
         return out;
@@ -189,7 +196,11 @@ class RFTrainer {
                     const std::vector<uint32_t>& root_ids, uint32_t nf, const std::vector<uint32_t>& feats, Model& out) {
         const uint32_t T = t1 - t0;
         std::string err;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        auto tb0 = tnow();
         if (!dev.rf_begin(root_off, root_ids, nf, feats, &err)) fail_str(err);
+        stats_.t_begin += secs(tb0, tnow());
         std::vector<std::shared_ptr<TreeNode>> roots(T);
         std::vector<Open> open;
         uint32_t next_key = T;  // keys 0..T-1 are the roots
@@ -210,7 +221,10 @@ class RFTrainer {
             }
             std::vector<frdev::DeviceDataset::RfCand> cands;
             std::vector<float> lab;
+            auto tl0 = tnow();
             if (!dev.rf_level(active, slot_of_key, k, p_.split_method, p_.min_leaf_support, &cands, &lab, &err)) fail_str(err);
+            auto tl1 = tnow();
+            stats_.t_level += secs(tl0, tl1);
             stats_.levels++;
             stats_.candidates += cands.size();
             std::vector<frdev::DeviceDataset::RfSplit> splits(open.size());
@@ -272,7 +286,10 @@ class RFTrainer {
                 stats_.nodes += 2;
             }
             std::vector<double> child_out;
+            auto tp0 = tnow();
+            stats_.t_select += secs(tl1, tp0);
             if (!dev.rf_split(splits, &child_out, &err)) fail_str(err);
+            stats_.t_split += secs(tp0, tnow());
             for (const Pending& pd : pend) {
                 const Open& o = open[pd.a];
                 TreeNode* kids[2] = {o.node->lhs.get(), o.node->rhs.get()};
