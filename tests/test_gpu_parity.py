@@ -906,8 +906,8 @@ def test_verify_kernel_accepts_ties_inside_one_gain_class(monkeypatch):
 def test_verify_kernel_orders_exact_duplicates_by_the_tie_break(monkeypatch):
     """Documents of a query with bit-identical feature rows score exactly alike under every weight vector, so the
     reference orders them by its tie-break (gain ascending).  Their duplicate-group id rides in the keys next to the
-    gain class, the class ids descend with the gain, and the verify kernel then KEEPS a close pair of one group even
-    when the gains differ (positive keys; kernels_verify.inc).  Same trajectory as the oracle, far fewer pairs redone
+    gain class, the class ids descend with the gain, and the verify kernel then KEEPS a tied cluster of two to four
+    documents of one group even when their gains differ (kernels_verify.inc).  Same trajectory as the oracle, far fewer pairs redone
     than without the groups (FR_NO_DUP_GROUPS=1, where every such pair goes to the exact kernel)."""
     rng = np.random.default_rng(97)
     X, y, qid = synth_dataset(97, 9000, 12, 90, max_len=200)
