@@ -38,8 +38,10 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=20000, help="documents verified against the CPU oracle")
+    ap.add_argument("--d", type=int, default=0, help="override the number of features (experiments on LDS occupancy)")
     args = ap.parse_args()
     n, d, q, seed = bench.SHAPES[args.shape]
+    d = args.d or d
     X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
     ds = fr.CDataset.from_numpy(X, y, qid)
     rng = np.random.default_rng(7)
