@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfastrank_amd.so")
 SOURCES = ["device.hip", "capi.cpp"]
 HEADERS = ["device.hpp", "host.hpp", "loader.hpp", "rf_train.hpp", "kernels_rf.inc", "json.hpp", os.path.join("..", "..", "include", "fastrank.h"),
-           "device_plumbing.inc", "kernels_score.inc", "kernels_tree.inc", "kernels_metric.inc",
+           "device_plumbing.inc", "kernels_score.inc", "kernels_tree.inc", "kernels_treerank.inc", "kernels_metric.inc",
            "kernels_linesearch.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "kernels_sortnet.inc", "kernels_fullverify.inc",
            "device_dataset.inc"]
 # -ffp-contract=off is a correctness flag, not a tuning flag: the reference's dot product is an

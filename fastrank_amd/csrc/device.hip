@@ -8,6 +8,7 @@
 //   kernels_score.inc       tile layout (xb_index) + score_linear_kernel (exact ordered f64 dot
 //                           product, lane = document), single-feature / axpy helpers
 //   kernels_tree.inc        tree_ensemble_lds_kernel (forest streamed through LDS, 8 walks per lane)
+//   kernels_treerank.inc    tree_ensemble_rank_kernel (threshold ranks instead of features: u16 codes, 32-bit heap nodes)
 //                           and tree_ensemble_kernel (L2 fallback)
 //   kernels_metric.inc      metric_sort_kernel (LDS bitonic sort + NDCG/AP/RR in the reference's
 //                           summation order) and the fixed-shape mean reduction
@@ -46,6 +47,7 @@ namespace frdev {
 #include "device_plumbing.inc"
 #include "kernels_score.inc"
 #include "kernels_tree.inc"
+#include "kernels_treerank.inc"
 #include "kernels_metric.inc"
 #include "kernels_linesearch.inc"
 #include "kernels_verify.inc"

@@ -199,6 +199,7 @@ class DeviceDataset {
 
   private:
     DeviceDataset();
+    bool try_score_trees_rank(const FlatTrees& trees, std::string* err);
     bool try_score_trees_lds(const FlatTrees& trees, std::string* err);
     bool try_score_trees_lds_shape(const FlatTrees& trees, const void* shape, std::string* err);
     struct Impl;

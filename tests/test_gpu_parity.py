@@ -627,11 +627,51 @@ def test_tree_kernel_block_shapes(mslr_small, shape, monkeypatch):
     X, y, qid, g, c = mslr_small
     if shape:
         monkeypatch.setenv("FR_TREE_SHAPE", shape)
+        monkeypatch.setenv("FR_TREE_RANK", "0")  # the f32 walk; "" is the default path (threshold ranks)
     rng = np.random.default_rng(21)
     trees = [_rand_tree(rng, X, 7, nfeat=X.shape[1] + 4) for _ in range(77)]
     weights = rng.uniform(-1.0, 1.0, len(trees)).tolist()
     got = native.predict_scores_dense(_ensemble(trees, weights), g)
     assert np.array_equal(got, c.score_ensemble(trees, weights))
+
+
+def _tree_kernels_used(model, g):
+    native.profile_reset()
+    native.profile_enable(True)
+    try:
+        out = native.predict_scores_dense(model, g)
+    finally:
+        native.profile_enable(False)
+    return out, {k for k in native.profile_stats() if k.startswith("tree_")}
+
+
+def test_tree_rank_kernel(mslr_small, small):
+    """The threshold-rank walk (kernels_treerank.inc) against the oracle, bit for bit, and that it is the kernel that
+    ran: ragged last batches, missing features, negative weights; trees of depth 9 and 10 (fewer walks per thread);
+    more than 255 and more than 511 distinct thresholds on a feature (tables staged two / one feature per round);
+    forests outside the encoding (a leaf deeper than 10, > 1023 thresholds on a feature) take the f32 walks."""
+    X, y, qid, g, c = mslr_small
+    rng = np.random.default_rng(23)
+    trees = [_rand_tree(rng, X, 7, nfeat=X.shape[1] + 4) for _ in range(77)]
+    weights = rng.uniform(-1.0, 1.0, len(trees)).tolist()
+    got, used = _tree_kernels_used(_ensemble(trees, weights), g)
+    assert used == {"tree_rank_kernel"} and np.array_equal(got, c.score_ensemble(trees, weights))
+    for depth, count in ((9, 21), (10, 7), (2, 300)):
+        trees = [_rand_tree(rng, X, depth, p_leaf=0.03) for _ in range(count)]
+        weights = rng.uniform(0.0, 1.0, count).tolist()
+        got, used = _tree_kernels_used(_ensemble(trees, weights), g)
+        assert used == {"tree_rank_kernel"} and np.array_equal(got, c.score_ensemble(trees, weights)), depth
+    X, y, qid, g, c = small
+    nf = X.shape[1]
+    for count, path in ((6 * nf, "tree_rank_kernel"), (12 * nf, "tree_rank_kernel"), (24 * nf, "tree_ensemble_kernel")):
+        # ~63 split nodes per tree, thresholds drawn from a continuous quantile: count * 63 / nf distinct per feature
+        trees = [_rand_tree(rng, X, 6, p_leaf=0.0) for _ in range(count)]
+        weights = [1.0] * count
+        got, used = _tree_kernels_used(_ensemble(trees, weights), g)
+        assert used == {path} and np.array_equal(got, c.score_ensemble(trees, weights)), count
+    deep = [_rand_tree(rng, X, 11, p_leaf=0.0) for _ in range(2)]
+    got, used = _tree_kernels_used(_ensemble(deep, [1.0, 0.5]), g)
+    assert "tree_rank_kernel" not in used and np.array_equal(got, c.score_ensemble(deep, [1.0, 0.5]))
 
 
 def test_tree_kernel_edge_forests(small):
