@@ -674,6 +674,26 @@ def test_tree_rank_kernel(mslr_small, small):
     assert "tree_rank_kernel" not in used and np.array_equal(got, c.score_ensemble(deep, [1.0, 0.5]))
 
 
+def test_tree_rank_kernel_slot_layouts(mslr_small):
+    """Codes sit two slots to a 32-bit word and the constant slots follow the last feature's: forests over 1, 2, 3, 5
+    and 7 distinct features (odd and even slot counts, the constant slots sharing / not sharing a word with a feature;
+    float4 groups with one to four ranked features, searched deepest table first) against the oracle, bit for bit."""
+    X, y, qid, g, c = mslr_small
+    rng = np.random.default_rng(29)
+    for feats in ([5], [2, 3], [0, 1, 6], [1, 4, 5, 6, 7], [0, 2, 3, 8, 9, 10, 11], list(range(9, 20))):
+        def grow(depth):
+            if depth == 0 or rng.random() < 0.08:
+                return {"LeafNode": float(rng.uniform(-2, 4))}
+            f = int(feats[rng.integers(0, len(feats))])
+            # very different table depths inside one float4 group: feature ids divisible by 3 take few thresholds
+            q = float(rng.integers(1, 4)) / 4.0 if f % 3 == 0 else float(rng.random())
+            return {"FeatureSplit": {"fid": f, "split": float(np.quantile(X[:, f], q)), "lhs": grow(depth - 1), "rhs": grow(depth - 1)}}
+        trees = [grow(6) for _ in range(41)]
+        weights = rng.uniform(-1.0, 1.0, len(trees)).tolist()
+        got, used = _tree_kernels_used(_ensemble(trees, weights), g)
+        assert used == {"tree_rank_kernel"} and np.array_equal(got, c.score_ensemble(trees, weights)), feats
+
+
 def test_tree_kernel_edge_forests(small):
     X, y, qid, g, c = small
     rng = np.random.default_rng(22)
