@@ -3,22 +3,44 @@
 The library is the product: every public call in this package goes through it.  There is no
 Python/NumPy/CPU implementation to fall back to -- if the library is missing or no GPU is
 visible, compute calls raise.
+
+The objects are compiled in parallel (fullverify.hip once per slice of the size classes of the full-ranking kernel:
+-DFV_PART=k) and cached under fastrank_amd/build/ by source time stamps, so editing one kernel family rebuilds one or
+a few objects.
 """
+import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+OBJ_DIR = os.path.join(_HERE, "build")
 LIB_PATH = os.path.join(_HERE, "libfastrank_amd.so")
-SOURCES = ["device.hip", "capi.cpp"]
-HEADERS = ["device.hpp", "host.hpp", "loader.hpp", "rf_train.hpp", "kernels_rf.inc", "json.hpp", os.path.join("..", "..", "include", "fastrank.h"),
-           "device_plumbing.inc", "kernels_score.inc", "kernels_tree.inc", "kernels_treerank.inc", "kernels_metric.inc",
-           "kernels_linesearch.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "kernels_sortnet.inc", "kernels_fullverify.inc",
-           "device_dataset.inc"]
+INCLUDE = os.path.join("..", "..", "include", "fastrank.h")
+DEVICE_INCS = ["device.hpp", "fullverify.hpp", "device_plumbing.inc", "kernels_score.inc", "kernels_tree.inc", "kernels_treerank.inc", "kernels_metric.inc",
+               "kernels_linesearch.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "kernels_rf.inc", "device_dataset.inc"]
+FV_INCS = ["device.hpp", "fullverify.hpp", "kernels_sortnet.inc", "kernels_fullverify.inc"]
+HOST_INCS = ["device.hpp", "host.hpp", "loader.hpp", "rf_train.hpp", "json.hpp", INCLUDE]
+
+
+def fv_parts() -> int:
+    txt = open(os.path.join(CSRC, "fullverify.hpp")).read()
+    return int(re.search(r"FV_PARTS\s*=\s*(\d+)", txt).group(1))
+
+
+def units():
+    """(object name, source, extra flags, dependencies)"""
+    out = [("device.o", "device.hip", [], DEVICE_INCS), ("capi.o", "capi.cpp", [], HOST_INCS)]
+    for k in range(fv_parts()):
+        out.append(("fullverify_%d.o" % k, "fullverify.hip", ["-DFV_PART=%d" % k], FV_INCS))
+    return out
+
+
 # -ffp-contract=off is a correctness flag, not a tuning flag: the reference's dot product is an
 # unfused f64 multiply-then-add (src/dense_dataset.rs:71-74) and rank order must be bit-exact.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -29,25 +51,74 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (needed to build libfastrank_amd.so for gfx950)")
 
 
+def _extra_flags():
+    return os.environ.get("FR_BUILD_FLAGS", "").split()  # kernel-tuning experiments (-DFV_... ...)
+
+
+def _stale(obj, src, deps) -> bool:
+    path = os.path.join(OBJ_DIR, obj)
+    if not os.path.exists(path):
+        return True
+    built = os.path.getmtime(path)
+    flag_file = path + ".flags"
+    if not os.path.exists(flag_file) or open(flag_file).read() != " ".join(_extra_flags()):
+        return True
+    files = [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in deps]
+    return any(os.path.exists(p) and os.path.getmtime(p) > built for p in files)
+
+
 def needs_build() -> bool:
+    """The library is current if it is newer than every source (the objects are a cache: a tree that travelled without
+    fastrank_amd/build/, e.g. to the GPU box, is not rebuilt)."""
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(p) and os.path.getmtime(p) > built for p in deps)
+    flag_file = LIB_PATH + ".flags"
+    if (open(flag_file).read() if os.path.exists(flag_file) else "") != " ".join(_extra_flags()):
+        return True
+    for _, src, _, deps in units():
+        files = [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in deps]
+        if any(os.path.exists(p) and os.path.getmtime(p) > built for p in files):
+            return True
+    return False
+
+
+def _compile(hipcc, obj, src, extra, verbose):
+    path = os.path.join(OBJ_DIR, obj)
+    cmd = [hipcc] + FLAGS + _extra_flags() + extra + ["-c", os.path.join(CSRC, src), "-o", path + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed on %s %s:\n%s" % (src, " ".join(extra), proc.stdout))
+    os.replace(path + ".tmp", path)
+    with open(path + ".flags", "w") as fh:
+        fh.write(" ".join(_extra_flags()))
+    return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    extra = os.environ.get("FR_BUILD_FLAGS", "").split()  # kernel-tuning experiments (-DFV_WAVES_64=2 ...)
-    cmd = [hipcc_path()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp", "-lz"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = hipcc_path()
+    todo = [(o, s, e) for o, s, e, d in units() if force or _stale(o, s, d)]
+    jobs = max(1, min(len(todo), int(os.environ.get("FR_BUILD_JOBS", str(os.cpu_count() or 4)))))
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+            futs = [pool.submit(_compile, hipcc, o, s, e, verbose) for o, s, e in todo]
+            for f in futs:
+                f.result()
+    objs = [os.path.join(OBJ_DIR, o) for o, _, _, _ in units()]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp", "-lz"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout)
+        raise RuntimeError("link failed:\n" + proc.stdout)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(LIB_PATH + ".flags", "w") as fh:
+        fh.write(" ".join(_extra_flags()))
     return LIB_PATH
 
 

@@ -17,15 +17,18 @@
 //                           kernel recomputes the pairs it cannot verify)
 //   kernels_fullrank.inc    linesearch_scores_kernel + rank_metric_kernel: AP / RR / depth-less NDCG
 //   kernels_rr.inc          rr_verify_kernel / rr_exact_kernel: reciprocal rank by bound-and-verify
-//   kernels_sortnet.inc     (generated, tools/gen_sortnet.py) compare-exchange networks over register-resident keys
-//   kernels_fullverify.inc  fullrank_verify_kernel: NDCG of any depth / AP by sorting approximate keys in registers
-//                           and verifying the gaps (the exact kernels of kernels_fullrank.inc redo what fails)
+//   fullverify.hpp          interface to fullverify.hip (own objects, compiled per slice of the size classes):
+//     kernels_sortnet.inc     (generated, tools/gen_sortnet.py) compare-exchange networks over register-resident keys
+//     kernels_fullverify.inc  fullrank_verify_kernel: NDCG of any depth / AP by sorting approximate keys in registers
+//                             and verifying the gaps (the exact kernels of kernels_fullrank.inc redo what fails)
 //   kernels_rf.inc          random-forest TRAINING: level-synchronous split search over a batch of trees (rocPRIM radix sort +
 //                           sequential-association importance kernels)
 //   device_dataset.inc      DeviceDataset: HBM layout (runs, tiles, tables) and every launcher
 #include "device.hpp"
 
 #include <hip/hip_runtime.h>
+
+#include "fullverify.hpp"
 
 #include <cstring>
 
@@ -53,8 +56,6 @@ namespace frdev {
 #include "kernels_verify.inc"
 #include "kernels_fullrank.inc"
 #include "kernels_rr.inc"
-#include "kernels_sortnet.inc"
-#include "kernels_fullverify.inc"
 #include "kernels_rf.inc"
 #include "device_dataset.inc"
 
