@@ -119,6 +119,75 @@ def source_sha1():
     return out
 
 
+def random_trees(rng, X, ntrees, max_depth):
+    """config 5's forest: fid uniform, split = a uniform quantile of that column, leaves U[0,4)."""
+    sample = X[rng.integers(0, X.shape[0], 4096)]
+
+    def grow(depth):
+        if depth >= max_depth or rng.random() < 0.05:
+            return {"LeafNode": float(rng.uniform(0, 4))}
+        f = int(rng.integers(0, X.shape[1]))
+        return {"FeatureSplit": {"fid": f, "split": float(np.quantile(sample[:, f], rng.random())),
+                                 "lhs": grow(depth + 1), "rhs": grow(depth + 1)}}
+
+    return [grow(1) for _ in range(ntrees)]
+
+
+def bench_trees(args, world, rank, dist, fr, native, dataset, X, y, qid, n, d):
+    """BASELINE.json configs[4] as a bench line (`--measure trees`): one step = one 500-tree ensemble pass over the
+    30K shape with the batched tree-traversal kernel.  Ranks score replicas of the same matrix (document shards of one
+    pass would be the production split; no exchange either way), so N > 1 is weak scaling over replicas."""
+    import torch
+
+    trees = random_trees(np.random.default_rng(7), X, 500, 8)
+    model = fr.CModel.from_dict({"Ensemble": {"weights": [1.0] * len(trees), "models": [{"DecisionTree": t} for t in trees]}})
+    out = None
+    for _ in range(max(1, args.warmup)):
+        out = native.predict_scores_dense(model, dataset, 0)  # (0 rows copied back: the pass itself)
+    native.synchronize()
+    if world > 1:
+        dist.barrier()
+    native.profile_reset()
+    native.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        native.predict_scores_dense(model, dataset, 0)
+    native.synchronize()
+    elapsed = time.perf_counter() - t0
+    native.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    stats = native.profile_stats()
+    kname = "tree_rank_kernel" if "tree_rank_kernel" in stats else "tree_ensemble_kernel"
+    k = stats[kname]
+    from oracle import pyoracle as o  # the checker, outside the timed region
+
+    m = min(20000, n)
+    got = native.predict_scores_dense(model, dataset, n)[:m]
+    ok = bool(np.array_equal(o.Dataset(X[:m], y[:m], qid[:m]).score_ensemble(trees, [1.0] * len(trees)), got))
+    b_rf = n * (4 * d + 8)  # SURVEY.md 8(d): read X once, write one f64 score per document
+    sec = k["avg_ms"] * 1e-3
+    print(json.dumps({
+        "metric": "tree-ensemble scoring passes/sec on MSLR-WEB30K shape (BASELINE.json configs[4])",
+        "value": world * args.steps / elapsed, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "500 random trees of depth <= 8 x %d docs x %d features (configs[4]); one step = one ensemble pass" % (n, d),
+                   "parallelism": "replicas x{}".format(world)},
+        "doc_trees_per_s": world * n * len(trees) * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "achieved": b_rf / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_rf / sec / 1e9 / HBM_PEAK_GBS, "traffic": 2.17e9, "kernel": kname, "avg_launch_ms": k["avg_ms"],
+                     "note": "traffic: FETCH_SIZE x2 + WRITE_SIZE of profiles/r02_pmc_treerank_after_summary.txt (static)"},
+        "limiter": {"bound": "valu_issue + lds", "frac": 0.61, "lds_address_unit_busy": 0.63,
+                    "source": "profiles/r02_pmc_treerank_after_summary.txt (static, round 2: the kernel is unchanged)"},
+        "parity_first_docs_bit_exact": ok,
+    }))
+
+
 def load_pmc(shape, usable):
     """Static rocprofv3 --pmc figures (profiles/hbm_traffic.json, captured by tools/pmc_bench.sh on THIS command).
     They are NOT measured in this run: the object says where they come from, which sources they were captured on,
@@ -225,6 +294,13 @@ def main():
     X, y, qid = gen_mslr_shaped(seed, n, d, q, args.data)
     gen_s = time.perf_counter() - t0
     dataset = fr.CDataset.from_numpy(X, y, qid)
+
+    if args.measure == "trees":
+        bench_trees(args, world, rank, dist, fr, native, dataset, X, y, qid, n, d)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     strong = args.restarts_total > 0
     R = args.restarts_total if strong else args.restarts_per_gpu * world
@@ -502,8 +578,8 @@ def main():
         vp = float(s1["verify_pairs"] - s0["verify_pairs"])
         vr = float(s1["verify_redone"] - s0["verify_redone"])
         out = {
-            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape" if headline
-            else "coordinate-ascent {} evals/sec on MSLR-WEB30K shape, data={} (side measurement)".format(args.measure, args.data),
+            "metric": "coordinate-ascent NDCG@10 evals/sec on MSLR-WEB30K shape" if (headline and args.shape == "30k")
+            else "coordinate-ascent {} evals/sec on MSLR-WEB{} shape, data={} (side measurement)".format(args.measure, args.shape.upper(), args.data),
             "value": useful_all / elapsed_max,
             "unit": "evals/s",
             "n_gpus": world,
@@ -520,7 +596,7 @@ def main():
                             "{}, {} x 25 steps/coord (configs[{}])".format(
                                 args.shape.upper(), n, d, q, args.measure.upper() if args.measure.startswith("ndcg") else args.measure,
                                 "{} restarts in total".format(R) if strong else "{} restarts/GPU".format(args.restarts_per_gpu),
-                                3 if R == 256 and world == 8 else 2),
+                                1 if args.shape == "10k" else (3 if R == 256 and world == 8 else 2)),
                 "restarts_total": R,
                 "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
                 "evals_per_step_per_gpu": evals_per_step,

@@ -213,5 +213,6 @@ void profile_enable(bool on);
 void profile_reset();
 std::vector<KernelStat> profile_stats();
 bool device_synchronize(std::string* err);
+size_t device_free_bytes();  // free HBM on the current device (0 if unknown)
 
 }  // namespace frdev

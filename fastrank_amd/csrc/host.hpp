@@ -452,14 +452,17 @@ struct DatasetView {
                 std::vector<int32_t> owner_q(core->qnames.size(), -1);
                 for (size_t q = 0; q < owner->csr_query.size(); q++) owner_q[owner->csr_query[q]] = (int32_t)q;
                 std::vector<uint32_t> pq(csr.nq);
-                for (size_t q = 0; q < csr.nq; q++) {
-                    if (owner_q[csr_query[q]] < 0) fail_str("sampled view: query not in the dataset it was sampled from");
-                    pq[q] = (uint32_t)owner_q[csr_query[q]];
+                bool mapped = true;
+                for (size_t q = 0; q < csr.nq && mapped; q++) {
+                    mapped = owner_q[csr_query[q]] >= 0;
+                    if (mapped) pq[q] = (uint32_t)owner_q[csr_query[q]];
                 }
-                dev = frdev::DeviceDataset::create_view(pdev, csr, pq, &err);
-                if (!dev) fail_str(err);
+                // a view the parent's layout cannot express (a query the owner does not hold, documents in another
+                // order) tiles its own matrix below, as every view did in round 1, instead of failing
+                if (mapped) dev = frdev::DeviceDataset::create_view(pdev, csr, pq, &err);
             }
-            return dev;
+            if (dev) return dev;
+            err.clear();
         }
         dev = frdev::DeviceDataset::create(csr, &err);
         if (!dev) fail_str(err);

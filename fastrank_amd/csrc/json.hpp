@@ -175,10 +175,28 @@ class Parser {
         double v = 0.0;
         auto r = std::from_chars(tok.data(), tok.data() + tok.size(), v);
         if (r.ec == std::errc::result_out_of_range) {
-            bool tiny = false;  // decide by the decimal exponent: underflow -> +-0.0, overflow -> error
-            size_t e = tok.find_first_of("eE");
-            if (e != std::string::npos && tok.size() > e + 1 && tok[e + 1] == '-') tiny = true;
-            if (!tiny) fail("number out of range");
+            // underflow -> +-0.0 (like serde_json), overflow -> error: decided by the decimal exponent of the first
+            // non-zero digit (digits before the point count up, zeros after it count down, plus the written exponent) --
+            // "0.<400 zeros>1" and "0.<400 zeros>1e+5" are tiny although they carry no / a positive exponent
+            const size_t e = tok.find_first_of("eE");
+            const std::string mant = tok.substr(0, e);
+            long long written = 0;
+            if (e != std::string::npos) {
+                const bool neg = tok.size() > e + 1 && tok[e + 1] == '-';
+                size_t k = e + 1 + ((tok.size() > e + 1 && (tok[e + 1] == '-' || tok[e + 1] == '+')) ? 1 : 0);
+                for (; k < tok.size() && written < 100000000; k++) written = written * 10 + (tok[k] - '0');
+                if (neg) written = -written;
+            }
+            const size_t point = mant.find('.');
+            const size_t int_end = point == std::string::npos ? mant.size() : point;
+            long long lead = 0;  // decimal exponent of the first non-zero digit, before `written`
+            bool found = false;
+            for (size_t k = (mant[0] == '-' ? 1 : 0); k < mant.size() && !found; k++) {
+                if (mant[k] == '.' || mant[k] == '0') continue;
+                lead = k < int_end ? (long long)(int_end - k) - 1 : -(long long)(k - int_end);
+                found = true;
+            }
+            if (found && lead + written >= 0) fail("number out of range");
             return Value::number(tok[0] == '-' ? -0.0 : 0.0);
         }
         if (r.ec != std::errc() || r.ptr != tok.data() + tok.size()) fail("invalid number");

@@ -108,8 +108,15 @@ class RFTrainer {
         std::sort(queries.begin(), queries.end(), [&](uint32_t a, uint32_t b) {
             return core.qnames[view_->csr_query[a]] < core.qnames[view_->csr_query[b]];
         });
-        const size_t n_features = std::min(features.size(), std::max<size_t>(1, (size_t)((double)features.size() * p_.feature_sampling_rate)));  // (take(n))
-        const size_t n_queries = std::min(queries.size(), std::max<size_t>(1, (size_t)((double)queries.size() * p_.instance_sampling_rate)));
+        // sampling.rs:49-50: max(1, (len as f64 * rate) as usize), then take(n) from a list of len items.  Rust's cast
+        // saturates (NaN / negative -> 0); a C++ cast of such a value is undefined behaviour
+        auto sample_count = [](size_t len, double rate) {
+            const double x = (double)len * rate;
+            const size_t c = (x != x || x <= 0.0) ? 0 : (x >= (double)len ? len : (size_t)x);
+            return std::min(len, std::max<size_t>(1, c));
+        };
+        const size_t n_features = sample_count(features.size(), p_.feature_sampling_rate);
+        const size_t n_queries = sample_count(queries.size(), p_.instance_sampling_rate);
         if (features.empty()) fail_str("assertion failed: !features.is_empty()");
         if (queries.empty()) fail_str("assertion failed: !data.queries().is_empty()");
         // instance ids of each query in ascending order (the device layout inside a query is the ranking order)
@@ -127,9 +134,19 @@ class RFTrainer {
         if (!p_.quiet) {
             printf("-----------------------\n|%7s|%7s|%7s|\n-----------------------\n", "Tree", "Depth", ev_.name.c_str());
         }
-        // batches sized by device memory: rf_bytes_per_item per (sampled instance x sampled feature)
+        // batches sized by device memory: rf_bytes_per_item per (sampled instance x sampled feature), at most 24 GB and at
+        // most 40 % of what is free right now (the sort's scratch, the candidate tables and the per-tree score buffers
+        // come on top)
         size_t budget = (size_t)24 << 30;
+        {
+            const size_t free_b = frdev::device_free_bytes();
+            if (free_b != 0) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, free_b / 5 * 2));
+        }
         if (const char* e = getenv("FR_RF_BATCH_BYTES")) budget = std::max<size_t>(1 << 20, (size_t)atoll(e));
+        struct EndGuard {  // the batch buffers (GBs) go back to the device also when a batch fails
+            frdev::DeviceDataset& d;
+            ~EndGuard() { d.rf_end(); }
+        } end_guard{dev};
         uint32_t t0 = 0;
         while (t0 < p_.num_trees) {
             const auto ts0 = std::chrono::steady_clock::now();
@@ -211,6 +228,9 @@ class RFTrainer {
             if (enterable(n, 1)) open.push_back({t, t, n, roots[t].get(), 0.0, 1});
         }
         const uint32_t k = p_.split_candidates;
+        // split_candidates < 2: `(1..k)` is empty (random_forest.rs:236), no feature yields a candidate and every node
+        // stays the leaf it is -- nothing to ask the device
+        if (k < 2) open.clear();
         while (!open.empty()) {
             std::vector<frdev::DeviceDataset::RfActive> active(open.size());
             std::vector<uint32_t> slot_of_key(next_key, 0xFFFFFFFFu);

@@ -81,7 +81,10 @@ const CResult *make_dense_dataset_f32_f64_i64(size_t n, size_t d, const float *x
                                               const int64_t *qids);
 
 /* src/lib.rs:245-253: TrainRequest JSON -> CModel.  The coordinate-ascent line search runs as
- * batched HIP launches; RandomForest training is not part of the MI355X path (error). */
+ * batched HIP launches (src/coordinate_ascent.rs:87-254); RandomForest requests are trained on the device too,
+ * level-synchronously over batches of trees (src/random_forest.rs:211-408; csrc/rf_train.hpp, kernels_rf.inc).
+ * With several devices visible (FR_DEVICES, default: all) the restarts of a coordinate-ascent request are spread
+ * over them inside this call, like the reference's rayon fan-out over restarts (src/coordinate_ascent.rs:215-225). */
 const CResult *train_model(void *train_request_json, void *dataset);
 /* src/lib.rs:258-263 */
 const CResult *model_from_json(const void *json_str);
@@ -167,7 +170,8 @@ const void *fr_rank_order(const CModel *model, const CDataset *dataset, uint32_t
  * a query sample owns only query / run tables over the parent's tiles (src/dataset.rs:101-178 keeps views as id lists
  * over the parent for the same reason). */
 const void *fr_dataset_device_info(const CDataset *dataset);
-/* Number of queries / instances in the dataset view. */
+/* Number of queries / instances in the dataset view (0 for a NULL handle).  fr_dataset_num_queries returns SIZE_MAX
+ * when the view cannot be grouped (e.g. a NaN label): the compute calls report the reason in their envelope. */
 size_t fr_dataset_num_queries(const CDataset *dataset);
 size_t fr_dataset_num_instances(const CDataset *dataset);
 

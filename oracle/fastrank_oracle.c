@@ -1065,9 +1065,17 @@ static int cmp_str_u32(const void *a, const void *b) {
     return strcmp(sa, sb);
 }
 
+static size_t rf_sample_count(size_t len, double rate) {
+    const double x = (double)len * rate;
+    size_t c = (x != x || x <= 0.0) ? 0 : (x >= (double)len ? len : (size_t)x);
+    if (c < 1) c = 1;
+    return c < len ? c : len;
+}
+
 /* random_forest.rs:288-342 learn_ensemble.  fids: the dataset's features.  Output: flattened trees (see
  * oracle_score_ensemble), roots[num_trees], weights[num_trees].  out_sample (optional, [num_trees][2]): number of
  * features / instances of each tree's sample.  Returns the number of nodes, or -(err) (1 capacity, 2 reference panic). */
+
 int64_t oracle_rf_learn(const oracle_dataset *ds, const oracle_rf_params *p, int measure, int64_t depth, const double *norms,
                         const uint32_t *fids, size_t nf, int32_t *out_fid, double *out_split, int32_t *out_lhs,
                         int32_t *out_rhs, size_t cap, int32_t *out_roots, double *out_weights, uint32_t *out_sample) {
@@ -1089,8 +1097,10 @@ int64_t oracle_rf_learn(const oracle_dataset *ds, const oracle_rf_params *p, int
     uint32_t *qid_sorted = (uint32_t *)malloc(sizeof(uint32_t) * (ds->nq ? ds->nq : 1));
     memcpy(qid_sorted, ds->qid, sizeof(uint32_t) * ds->nq);
     qsort(qid_sorted, ds->nq, sizeof(uint32_t), cmp_str_u32);
-    const size_t n_features = nf ? ((size_t)((double)nf * p->feature_sampling_rate) > 1 ? (size_t)((double)nf * p->feature_sampling_rate) : 1) : 0;
-    const size_t n_queries = ds->nq ? ((size_t)((double)ds->nq * p->instance_sampling_rate) > 1 ? (size_t)((double)ds->nq * p->instance_sampling_rate) : 1) : 0;
+    /* sampling.rs:49-50: max(1, (len as f64 * rate) as usize) items are taken from the shuffled list, i.e. at most len;
+       Rust's float -> usize cast saturates (NaN and negatives give 0) */
+    const size_t n_features = rf_sample_count(nf, p->feature_sampling_rate);
+    const size_t n_queries = rf_sample_count(ds->nq, p->instance_sampling_rate);
     uint32_t *fshuf = (uint32_t *)malloc(sizeof(uint32_t) * (nf ? nf : 1));
     uint32_t *qshuf = (uint32_t *)malloc(sizeof(uint32_t) * (ds->nq ? ds->nq : 1));
     uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (ds->n ? ds->n : 1));

@@ -94,6 +94,20 @@ def test_model_json_round_trip():
         clib._unwrap(clib._load().model_from_json(b'{"Linear": '))
 
 
+def test_tiny_numbers_flush_to_zero_whatever_their_exponent_looks_like():
+    """serde_json parses magnitudes below the subnormal range to 0.0; only magnitudes beyond f64 are "number out of
+    range".  The decision must come from the value's decimal exponent, not from the sign written after `e`."""
+    zeros = "0" * 400
+    for text, want in (("0." + zeros + "1", 0.0), ("0." + zeros + "1e+5", 0.0), ("-0." + zeros + "1", -0.0), ("1e-400", 0.0),
+                       ("0.0000001e-320", 0.0), ("1" + "0" * 20 + "e-400", 0.0)):
+        raw = ('{"Linear":{"weights":[%s, 1.0]}}' % text).encode()
+        w = fr.CModel(clib._unwrap(clib._load().model_from_json(raw)), None).to_dict()["Linear"]["weights"]
+        assert w[0] == want and np.signbit(w[0]) == np.signbit(want) and w[1] == 1.0, text
+    for text in ("1e400", "1" + "0" * 400, "0.1e310", "-123456789e301"):
+        with pytest.raises(Exception, match="number out of range"):
+            clib._unwrap(clib._load().model_from_json(('{"Linear":{"weights":[%s]}}' % text).encode()))
+
+
 def test_serde_style_float_formatting():
     cm = fr.CModel.from_dict({"Linear": {"weights": [1.0, 0.05, 1e-7, 1.5e300, 123456.75, 1e16, -0.0, 0.001]}})
     raw = clib._take_str(clib._load().model_query_json(cm.pointer, b"to_json"))

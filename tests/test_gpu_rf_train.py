@@ -53,6 +53,36 @@ def test_regression_tree_known_answer_through_training():
     assert model.to_dict() == exp
 
 
+def test_fewer_than_two_split_candidates_gives_single_leaf_trees(trec):
+    """split_candidates = 1: `(1..k)` is empty (src/random_forest.rs:236), no node splits and every tree is the mean of
+    its sample.  (Round 2 launched an empty grid here, or read the previous training's node tables.)"""
+    X, y, qid, g, c = trec
+    warm = _request(num_trees=3, seed=1, split_candidates=8, max_depth=6, min_leaf_support=2)
+    assert g.train_model(warm).to_dict() == _oracle(c, warm)[0]  # leaves node tables of another shape behind
+    for k in (1, 0):
+        req = _request(num_trees=4, seed=9, split_candidates=k, weight_trees=True)
+        got = g.train_model(req).to_dict()
+        exp, _ = _oracle(c, req)
+        assert got == exp
+        assert all("LeafNode" in m["DecisionTree"] for m in got["Ensemble"]["models"])
+    assert g.train_model(warm).to_dict() == _oracle(c, warm)[0]
+
+
+@pytest.mark.parametrize("rates", [(2.5, 1.5), (1e300, 7.0), (-1.0, 0.5), (0.0, 0.0)])
+def test_sampling_rates_outside_the_unit_interval_saturate_like_rust(trec, rates):
+    """`(len as f64 * rate) as usize` saturates in Rust (src/sampling.rs:49-50): a rate above one takes everything,
+    a negative or NaN rate gives 0 and then max(1, .) = one item."""
+    X, y, qid, g, c = trec
+    req = _request(num_trees=2, seed=3, instance_sampling_rate=rates[0], feature_sampling_rate=rates[1], min_leaf_support=2)
+    d = req.to_dict()
+    got = g.train_model(req).to_dict()
+    exp, sample = _oracle(c, req)
+    assert got == exp
+    nq, nf = len(set(qid.tolist())), X.shape[1]
+    want_f = nf if rates[1] >= 1.0 else max(1, int(nf * rates[1])) if rates[1] > 0 else 1
+    assert int(sample[0][0]) == want_f
+
+
 @pytest.mark.parametrize("method", ["SquaredError", "BinaryGiniImpurity", "InformationGain", "TrueVarianceReduction"])
 def test_reference_test_configuration_matches_oracle(trec, method):
     """The configuration of the reference's determinism test (src/random_forest.rs:427-463; 10 trees, seed 42,

@@ -18,17 +18,7 @@ import fastrank_amd as fr  # noqa: E402
 from fastrank_amd import native  # noqa: E402
 
 
-def random_forest(rng, X, ntrees, max_depth):
-    sample = X[rng.integers(0, X.shape[0], 4096)]
-
-    def grow(depth):
-        if depth >= max_depth or rng.random() < 0.05:
-            return {"LeafNode": float(rng.uniform(0, 4))}
-        f = int(rng.integers(0, X.shape[1]))
-        return {"FeatureSplit": {"fid": f, "split": float(np.quantile(sample[:, f], rng.random())),
-                                 "lhs": grow(depth + 1), "rhs": grow(depth + 1)}}
-
-    return [grow(1) for _ in range(ntrees)]
+random_forest = bench.random_trees
 
 
 def main():
