@@ -27,7 +27,11 @@ struct CQRel {
 
 namespace {
 
-std::mutex g_api_mu;  // one device job at a time per process (handles themselves are immutable)
+// Device jobs are serialised per dataset (DataCore::api_mu: the views of one core share device forms and work buffers),
+// not per process: two host threads that train on different datasets -- each on its own devices -- do not wait for
+// each other.  (Round 2 had one process-wide lock.)
+std::mutex g_stats_mu;  // fr_last_train_stats
+static std::mutex& api_mu_of(const CDataset& ds) { return ds.view->core->api_mu; }
 fr::TrainStats g_last_stats;
 
 // src/ffi.rs:40-43 return_string
@@ -149,6 +153,7 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("line_searches", Value::uint(s.line_searches));
     o.set("audit_values", Value::uint(s.audit_values));
     o.set("audit_mismatches", Value::uint(s.audit_mismatches));
+    o.set("devices", Value::uint(s.devices));
     return o;
 }
 
@@ -240,17 +245,31 @@ std::string rust_display_f64(double v) {
     return out;
 }
 
-fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq, uint32_t rbegin,
-                   uint32_t rend, std::vector<fr::RestartResult>* hist_out) {
+static void set_last_stats(const fr::TrainStats& st) {
+    std::lock_guard<std::mutex> lk(g_stats_mu);
+    g_last_stats = st;
+}
+
+// restarts [rbegin, rend) of a request on one device-side copy of the view (slot, device: DatasetView::device_ptr)
+static std::vector<fr::RestartResult> train_ca_range(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq,
+                                                     const fr::Evaluator& ev, uint32_t rbegin, uint32_t rend, int slot, int device,
+                                                     fr::TrainStats* stats_out) {
     auto t0 = std::chrono::steady_clock::now();
-    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
-    if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
-    fr::CATrainer trainer(view, std::move(ev), rq.ca, rbegin, rend);
+    fr::CATrainer trainer(view, ev, rq.ca, rbegin, rend, fr::QueryShard(), slot, device);
     while (trainer.run(64, nullptr)) {
     }
-    std::vector<fr::RestartResult> hist = trainer.results();
     trainer.stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    g_last_stats = trainer.stats();
+    if (stats_out) *stats_out = trainer.stats();
+    return trainer.results();
+}
+
+fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq, uint32_t rbegin,
+                   uint32_t rend, std::vector<fr::RestartResult>* hist_out) {
+    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+    if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+    fr::TrainStats st;
+    std::vector<fr::RestartResult> hist = train_ca_range(view, rq, ev, rbegin, rend, 0, -1, &st);
+    set_last_stats(st);
     fr::Model m;
     if (hist_out) {
         *hist_out = hist;
@@ -258,6 +277,148 @@ fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
         m = fr::ca_select(hist, rq.ca.output_ensemble);
     }
     return m;
+}
+
+// ---- train_model over the devices of a node -------------------------------------------------------------------------
+// The reference fans a request's restarts out over the host's cores inside the call (rayon, src/coordinate_ascent.rs:
+// 215-225).  Here the fan-out is over GPUs: FR_DEVICES (a comma list of ordinals; the same ordinal twice = two contexts
+// on one device) or, if unset, the device chosen with fr_set_device or else every visible device.  Restart ids are
+// block-partitioned (the child seeds are drawn in order from the master generator by every trainer, :211-213), each
+// device gets its own host thread, trainer and device-side copy of the dataset -- made device to device from the first
+// one (DeviceDataset::replicate, hipMemcpyPeer over xGMI) -- and the results are gathered in host memory and selected
+// like a single trainer's history (last maximum, or the score-weighted ensemble: :232-251).  No collective: this is
+// the in-process form of native.train_model_distributed.
+static int g_pinned_device = -1;  // fr_set_device: an explicit choice of ONE device for this process
+
+static std::vector<int> parse_device_list(const char* e, int count) {
+    std::vector<int> devs;
+    const char* p = e;
+    while (*p) {
+        while (*p == ',' || *p == ' ') p++;
+        if (!*p) break;
+        char* end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) fr::fail_str(std::string("FR_DEVICES: not a list of device ordinals: ") + e);
+        if (v < 0 || v >= count) fr::fail_str("FR_DEVICES: no device " + std::to_string(v) + " (" + std::to_string(count) + " visible)");
+        devs.push_back((int)v);
+        p = end;
+    }
+    if (devs.empty()) fr::fail_str("FR_DEVICES is empty");
+    return devs;
+}
+
+std::vector<int> fr_train_devices() {
+    const int count = frdev::device_count(nullptr);
+    if (const char* e = std::getenv("FR_DEVICES")) return parse_device_list(e, count);
+    if (g_pinned_device >= 0) return {g_pinned_device};
+    std::vector<int> devs;
+    for (int d = 0; d < count; d++) devs.push_back(d);
+    return devs;
+}
+
+// contiguous block partition of restart ids (first parts take the remainder), as native.shard_bounds
+static void restart_block(uint32_t R, uint32_t part, uint32_t parts, uint32_t* b, uint32_t* e) {
+    const uint32_t base = R / parts, rem = R % parts;
+    *b = part * base + std::min(part, rem);
+    *e = *b + base + (part < rem ? 1u : 0u);
+}
+
+// which entry of the device list trains which restarts, and on which device-side copy (slot 0 = the copy that exists
+// on `primary_dev`, if that device is listed)
+struct DevicePlan {
+    std::vector<int> devs, slot;
+    std::vector<uint32_t> begin, end;
+};
+static DevicePlan plan_devices(std::vector<int> devs, uint32_t R, int primary_dev) {
+    DevicePlan pl;
+    if (devs.size() > R) devs.resize(std::max<uint32_t>(R, 1));
+    const size_t k = devs.size();
+    pl.devs = devs;
+    pl.slot.assign(k, -1);
+    pl.begin.assign(k, 0);
+    pl.end.assign(k, 0);
+    int next_slot = 1;
+    bool primary_used = false;
+    for (size_t i = 0; i < k; i++) {
+        if (!primary_used && devs[i] == primary_dev) pl.slot[i] = 0, primary_used = true;
+        else pl.slot[i] = next_slot++;
+        restart_block(R, (uint32_t)i, (uint32_t)k, &pl.begin[i], &pl.end[i]);
+    }
+    return pl;
+}
+
+fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq) {
+    std::vector<int> devs = fr_train_devices();
+    const uint32_t R = rq.ca.num_restarts;
+    // a small matrix is not worth a context on every GPU (each costs a device-to-device copy and, the first time, the
+    // runtime's per-device start-up); an explicit FR_DEVICES is taken as given
+    if (!std::getenv("FR_DEVICES") && view->instances.size() * (size_t)view->core->d < (size_t(1) << 23)) devs.resize(std::min<size_t>(devs.size(), 1));
+    if (devs.size() > R) devs.resize(std::max<uint32_t>(R, 1));
+    if (devs.size() <= 1) {
+        if (!devs.empty() && (std::getenv("FR_DEVICES") || g_pinned_device >= 0)) {
+            std::string err;
+            if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
+        }
+        return train_ca(view, rq, 0, R, nullptr);
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+    if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+    // slot 0 is the device form the view already has (or builds now, on the first listed device); every other entry of
+    // the list gets the next slot
+    {
+        std::string err;
+        if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
+    }
+    const DevicePlan pl = plan_devices(devs, R, view->device_ptr()->device_ordinal());
+    const size_t k = pl.devs.size();
+    const std::vector<int>& slot = pl.slot;
+    std::vector<std::vector<fr::RestartResult>> parts(k);
+    std::vector<fr::TrainStats> stats(k);
+    std::vector<std::exception_ptr> errors(k);
+    auto work = [&](size_t i) {
+        try {
+            const uint32_t b = pl.begin[i], e = pl.end[i];
+            std::string err;
+            if (!frdev::set_device(devs[i], &err)) fr::fail_str(err);
+            parts[i] = train_ca_range(view, rq, ev, b, e, slot[i], devs[i], &stats[i]);
+        } catch (...) {
+            errors[i] = std::current_exception();
+        }
+    };
+    // the copies are made one after the other (they all read the first device's HBM), the training runs concurrently
+    for (size_t i = 0; i < k; i++) {
+        try {
+            (void)view->device_ptr(slot[i], devs[i]);
+        } catch (...) {
+            errors[i] = std::current_exception();
+        }
+    }
+    for (size_t i = 0; i < k; i++)
+        if (errors[i]) std::rethrow_exception(errors[i]);
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < k; i++) pool.emplace_back(work, i);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (size_t i = 0; i < k; i++)
+        if (errors[i]) std::rethrow_exception(errors[i]);
+    std::vector<fr::RestartResult> hist;
+    fr::TrainStats total = stats[0];
+    for (size_t i = 0; i < k; i++) {
+        hist.insert(hist.end(), parts[i].begin(), parts[i].end());
+        if (i == 0) continue;
+        total.useful_evals += stats[i].useful_evals, total.raw_evals += stats[i].raw_evals;
+        total.ticks = std::max(total.ticks, stats[i].ticks), total.groups += stats[i].groups;
+        total.restarts += stats[i].restarts;
+        total.verify_pairs += stats[i].verify_pairs, total.verify_redone += stats[i].verify_redone;
+        total.line_searches += stats[i].line_searches, total.exact_ticks += stats[i].exact_ticks;
+        total.audit_values += stats[i].audit_values, total.audit_mismatches += stats[i].audit_mismatches;
+    }
+    std::sort(hist.begin(), hist.end(), [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });
+    total.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    total.devices = (uint32_t)k;
+    set_last_stats(total);
+    return fr::ca_select(hist, rq.ca.output_ensemble);
 }
 
 // json_api.rs:41-48 -> random_forest::learn_ensemble
@@ -274,7 +435,7 @@ fr::Model train_rf(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     st.groups = trainer.stats().batches;
     st.raw_evals = trainer.stats().candidates;  // split candidates evaluated
     st.useful_evals = trainer.stats().nodes;    // tree nodes produced
-    g_last_stats = st;
+    set_last_stats(st);
     return m;
 }
 
@@ -504,10 +665,10 @@ const CResult* train_model(void* train_request_json, void* dataset) {
         // result_train_model reports the null dataset first (src/ffi.rs:189-193)
         const CDataset& ds = require_dataset(dataset);
         ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         auto* out = new CModel();
         try {
-            out->actual = rq.is_ca ? train_ca(ds.view, rq, 0, rq.ca.num_restarts, nullptr) : train_rf(ds.view, rq);
+            out->actual = rq.is_ca ? train_ca_devices(ds.view, rq) : train_rf(ds.view, rq);
         } catch (...) {
             delete out;
             throw;
@@ -545,7 +706,7 @@ const void* evaluate_by_query(const CModel* model, const CDataset* dataset, cons
         const CModel& m = require_model(model);
         const CDataset& ds = require_dataset(dataset);
         std::string name = accept_str("evaluator_name", evaluator);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
         Value o = Value::object();
@@ -567,7 +728,7 @@ const void* predict_scores(const CModel* model, const CDataset* dataset) {
     return json_call([&]() {
         const CModel& m = require_model(model);
         const CDataset& ds = require_dataset(dataset);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         if (view.instances.empty()) return std::string("{}");
         frdev::DeviceDataset& dev = view.device();
@@ -602,7 +763,7 @@ const void* predict_to_trecrun(const CModel* model, const CDataset* dataset, con
         const CDataset& ds = require_dataset(dataset);
         std::string path = accept_str("output_path", output_path);
         std::string sysname = accept_str("system_name", system_name);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         // src/json_api.rs:75-120
         std::ofstream out(path);
@@ -645,9 +806,34 @@ const void* predict_to_trecrun(const CModel* model, const CDataset* dataset, con
 
 int fr_device_count(void) { return frdev::device_count(nullptr); }
 
+// How train_model would spread `num_restarts` restarts over the devices of `devices_csv` (the FR_DEVICES syntax) on a
+// node with `device_count` devices whose first device form lives on `primary_device`: {"devices","slots","blocks"}.
+// No device is touched (the CPU tests check the partition and the list parsing with it).
+const void* fr_debug_device_plan(const void* devices_csv, int device_count, uint32_t num_restarts, int primary_device) {
+    return json_call([&]() {
+        const std::string csv = accept_str("devices_csv", devices_csv);
+        const DevicePlan pl = plan_devices(parse_device_list(csv.c_str(), device_count), num_restarts, primary_device);
+        Value o = Value::object(), d = Value::array(), sl = Value::array(), bl = Value::array();
+        for (size_t i = 0; i < pl.devs.size(); i++) {
+            d.push(Value::uint((uint64_t)pl.devs[i]));
+            sl.push(Value::uint((uint64_t)pl.slot[i]));
+            Value b = Value::array();
+            b.push(Value::uint(pl.begin[i]));
+            b.push(Value::uint(pl.end[i]));
+            bl.push(std::move(b));
+        }
+        o.set("devices", std::move(d));
+        o.set("slots", std::move(sl));
+        o.set("blocks", std::move(bl));
+        return frjson::dump(o);
+    });
+}
+
 int fr_set_device(int ordinal) {
     std::string err;
-    return frdev::set_device(ordinal, &err) ? 0 : 1;
+    if (!frdev::set_device(ordinal, &err)) return 1;
+    g_pinned_device = ordinal;  // train_model then stays on this device unless FR_DEVICES says otherwise
+    return 0;
 }
 
 const char* fr_version(void) { return "fastrank_amd 0.1.0 (fastrank C ABI 0.9.0-dev / python 0.7.0)"; }
@@ -658,12 +844,15 @@ const void* fr_train_model_shard(const void* train_request_json, const CDataset*
         const CDataset& ds = require_dataset(dataset);
         ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
         if (!rq.is_ca) fr::fail_str("fr_train_model_shard: only CoordinateAscent shards by restart");
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         std::vector<fr::RestartResult> hist;
         train_ca(ds.view, rq, restart_begin, restart_end, &hist);
         Value o = Value::object();
         o.set("restarts", restarts_to_json(hist));
-        o.set("stats", stats_to_json(g_last_stats));
+        {
+            std::lock_guard<std::mutex> slk(g_stats_mu);
+            o.set("stats", stats_to_json(g_last_stats));
+        }
         return frjson::dump(o);
     });
 }
@@ -671,6 +860,7 @@ const void* fr_train_model_shard(const void* train_request_json, const CDataset*
 struct FrTrainer {
     std::unique_ptr<fr::CATrainer> t;
     std::chrono::steady_clock::time_point t0;
+    std::shared_ptr<fr::DataCore> core;  // (its api_mu serialises the calls on this handle with other jobs on the dataset)
 };
 
 void* fr_ca_begin(const void* train_request_json, const CDataset* dataset, uint32_t restart_begin,
@@ -681,12 +871,13 @@ void* fr_ca_begin(const void* train_request_json, const CDataset* dataset, uint3
         const CDataset& ds = require_dataset(dataset);
         ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
         if (!rq.is_ca) fr::fail_str("fr_ca_begin: only CoordinateAscent");
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::Evaluator ev = fr::make_evaluator(*ds.view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
         if (ds.view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
         auto holder = std::make_unique<FrTrainer>();
         holder->t0 = std::chrono::steady_clock::now();
         holder->t = std::make_unique<fr::CATrainer>(ds.view, std::move(ev), rq.ca, restart_begin, restart_end);
+        holder->core = ds.view->core;
         h = holder.release();
     });
     if (st) {
@@ -705,7 +896,7 @@ void* fr_ca_begin_query_shard(const void* train_request_json, const CDataset* da
         ParsedRequest rq = parse_train_request(accept_str("train_request_json", train_request_json));
         if (!rq.is_ca) fr::fail_str("fr_ca_begin_query_shard: only CoordinateAscent");
         if (!allreduce) fr::fail_str("fr_ca_begin_query_shard: allreduce callback is null!");
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::Evaluator ev = fr::make_evaluator(*ds.view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
         if (total_queries == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
         fr::QueryShard shard;
@@ -716,6 +907,7 @@ void* fr_ca_begin_query_shard(const void* train_request_json, const CDataset* da
         auto holder = std::make_unique<FrTrainer>();
         holder->t0 = std::chrono::steady_clock::now();
         holder->t = std::make_unique<fr::CATrainer>(ds.view, std::move(ev), rq.ca, 0u, rq.ca.num_restarts, std::move(shard));
+        holder->core = ds.view->core;
         h = holder.release();
     });
     if (st) {
@@ -729,7 +921,7 @@ const void* fr_ca_step(void* trainer, uint64_t max_ticks, uint64_t* ticks_done, 
     return status_call([&]() {
         if (!trainer) fr::fail_str("trainer pointer is null!");
         FrTrainer* h = (FrTrainer*)trainer;
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(h->core->api_mu);
         uint64_t n = 0;
         const bool alive = h->t->run(max_ticks, &n);
         if (ticks_done) *ticks_done = n;
@@ -741,7 +933,7 @@ const void* fr_ca_state(void* trainer) {
     return json_call([&]() {
         if (!trainer) fr::fail_str("trainer pointer is null!");
         FrTrainer* h = (FrTrainer*)trainer;
-        std::lock_guard<std::mutex> lk(g_api_mu);  // fr_ca_step may be mutating the trainer on another thread
+        std::lock_guard<std::mutex> lk(h->core->api_mu);  // fr_ca_step may be mutating the trainer on another thread
         h->t->stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
         Value o = Value::object();
         o.set("restarts", restarts_to_json(h->t->results()));
@@ -780,14 +972,17 @@ const CResult* fr_select_model(const void* restarts_json, int output_ensemble) {
 }
 
 const void* fr_last_train_stats(void) {
-    return json_call([&]() { return frjson::dump(stats_to_json(g_last_stats)); });
+    return json_call([&]() {
+        std::lock_guard<std::mutex> slk(g_stats_mu);
+        return frjson::dump(stats_to_json(g_last_stats));
+    });
 }
 
 const void* fr_predict_scores_dense(const CModel* model, const CDataset* dataset, double* out, size_t out_len) {
     return status_call([&]() {
         const CModel& m = require_model(model);
         const CDataset& ds = require_dataset(dataset);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         if (view.instances.empty()) return;
         frdev::DeviceDataset& dev = view.device();
@@ -804,7 +999,7 @@ const void* fr_evaluate_dense(const CModel* model, const CDataset* dataset, cons
         const CModel& m = require_model(model);
         const CDataset& ds = require_dataset(dataset);
         std::string name = accept_str("evaluator_name", evaluator_name);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
         frdev::DeviceDataset& dev = view.device();
@@ -827,7 +1022,7 @@ const void* fr_rank_order(const CModel* model, const CDataset* dataset, uint32_t
     return status_call([&]() {
         const CModel& m = require_model(model);
         const CDataset& ds = require_dataset(dataset);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         frdev::DeviceDataset& dev = view.device();
         if (n < dev.n() || nq_plus_1 < dev.nq() + 1) fr::fail_str("fr_rank_order: output buffers too small");
@@ -856,7 +1051,7 @@ size_t fr_dataset_num_queries(const CDataset* dataset) {
 const void* fr_dataset_device_info(const CDataset* dataset) {
     return json_call([&]() {
         const CDataset& ds = require_dataset(dataset);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         std::shared_ptr<frdev::DeviceDataset> devp = ds.view->device_ptr();
         frdev::DeviceDataset& dev = *devp;
         fr::DatasetView* owner = ds.view->matrix_owner(nullptr);
@@ -883,7 +1078,7 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
     return status_call([&]() {
         const CDataset& ds = require_dataset(dataset);
         std::string name = accept_str("evaluator_name", evaluator_name);
-        std::lock_guard<std::mutex> lk(g_api_mu);
+        std::lock_guard<std::mutex> lk(api_mu_of(ds));
         fr::DatasetView& view = *ds.view;
         fr::Evaluator ev = fr::make_evaluator(view, name, qrel ? &qrel->actual : nullptr);
         frdev::DeviceDataset& dev = view.device();

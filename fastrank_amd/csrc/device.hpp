@@ -93,6 +93,10 @@ class DeviceDataset {
     // parent_query[q] = index of the view's query q in the parent.
     static std::shared_ptr<DeviceDataset> create_view(const std::shared_ptr<DeviceDataset>& parent, const HostCSR& csr,
                                                       const std::vector<uint32_t>& parent_query, std::string* err);
+    // A copy of `src` (which must own its matrix) in the HBM of device `device`, made device to device (hipMemcpyPeer);
+    // the same ordinal as the source gives a second, independent context on that device.
+    static std::shared_ptr<DeviceDataset> replicate(const std::shared_ptr<DeviceDataset>& src, int device, std::string* err);
+    int device_ordinal() const;
     bool shares_parent_matrix() const;
     ~DeviceDataset();
 

@@ -335,6 +335,9 @@ struct DataCore {
     std::vector<uint32_t> features;   // feature ids present (ascending)
     std::map<uint32_t, std::string> feature_names;
     bool is_dense_borrowed = false;
+    // One device job at a time per DATASET (every view of a core shares its device forms and their work buffers);
+    // calls on different datasets run concurrently -- each on the devices it was given.
+    std::mutex api_mu;
 
     std::string feature_name(uint32_t fid) const {
         auto it = feature_names.find(fid);
@@ -434,6 +437,18 @@ struct DatasetView {
         if (all_instances) *all_instances = all;
         return v;
     }
+    // queries of this view -> queries of the view that owns the matrix, through the core's query index (false: some
+    // query of this view is not one of the owner's)
+    bool owner_query_map(DatasetView* owner, std::vector<uint32_t>& pq) {
+        std::vector<int32_t> owner_q(core->qnames.size(), -1);
+        for (size_t q = 0; q < owner->csr_query.size(); q++) owner_q[owner->csr_query[q]] = (int32_t)q;
+        pq.resize(csr.nq);
+        for (size_t q = 0; q < csr.nq; q++) {
+            if (owner_q[csr_query[q]] < 0) return false;
+            pq[q] = (uint32_t)owner_q[csr_query[q]];
+        }
+        return true;
+    }
     std::shared_ptr<frdev::DeviceDataset> device_ptr() {
         std::lock_guard<std::mutex> lk(mu);
         if (dev) return dev;
@@ -448,18 +463,10 @@ struct DatasetView {
             if (all) {
                 dev = pdev;  // same documents: the parent's device dataset as it is
             } else {
-                // queries of this view -> queries of the owner, through the core's query index
-                std::vector<int32_t> owner_q(core->qnames.size(), -1);
-                for (size_t q = 0; q < owner->csr_query.size(); q++) owner_q[owner->csr_query[q]] = (int32_t)q;
-                std::vector<uint32_t> pq(csr.nq);
-                bool mapped = true;
-                for (size_t q = 0; q < csr.nq && mapped; q++) {
-                    mapped = owner_q[csr_query[q]] >= 0;
-                    if (mapped) pq[q] = (uint32_t)owner_q[csr_query[q]];
-                }
                 // a view the parent's layout cannot express (a query the owner does not hold, documents in another
                 // order) tiles its own matrix below, as every view did in round 1, instead of failing
-                if (mapped) dev = frdev::DeviceDataset::create_view(pdev, csr, pq, &err);
+                std::vector<uint32_t> pq;
+                if (owner_query_map(owner, pq)) dev = frdev::DeviceDataset::create_view(pdev, csr, pq, &err);
             }
             if (dev) return dev;
             err.clear();
@@ -468,7 +475,41 @@ struct DatasetView {
         if (!dev) fail_str(err);
         return dev;
     }
+    // The device form of this view in another context: slot 0 is device_ptr() (built on the device that was current at
+    // first use); slot k > 0 lives on device `device` and is a device-to-device copy of slot 0's matrix
+    // (DeviceDataset::replicate), or -- for a sampled view -- the same kind of view over its owner's copy there.
+    // train_model keeps one slot per device it spreads a request's restarts over (capi.cpp).
+    std::vector<std::shared_ptr<frdev::DeviceDataset>> replicas;  // [slot - 1]
+    std::shared_ptr<frdev::DeviceDataset> device_ptr(int slot, int device) {
+        if (slot <= 0) return device_ptr();
+        std::shared_ptr<frdev::DeviceDataset> primary = device_ptr();
+        bool all = true;
+        DatasetView* owner = matrix_owner(&all);
+        std::shared_ptr<frdev::DeviceDataset> owner_rep;
+        const bool aliases_owner = owner != this && (primary.get() == owner->device_ptr().get() || primary->shares_parent_matrix());
+        if (aliases_owner) owner_rep = owner->device_ptr(slot, device);
+        std::lock_guard<std::mutex> lk(mu);
+        if (replicas.size() < (size_t)slot) replicas.resize((size_t)slot);
+        std::shared_ptr<frdev::DeviceDataset>& r = replicas[(size_t)slot - 1];
+        if (r && r->device_ordinal() == device) return r;
+        r.reset();
+        std::string err;
+        if (aliases_owner) {
+            if (!primary->shares_parent_matrix()) {
+                r = owner_rep;
+            } else {
+                std::vector<uint32_t> pq;
+                if (!owner_query_map(owner, pq)) fail_str("sampled view: query not in the dataset it was sampled from");
+                r = frdev::DeviceDataset::create_view(owner_rep, csr, pq, &err);
+            }
+        } else {
+            r = frdev::DeviceDataset::replicate(primary, device, &err);
+        }
+        if (!r) fail_str(err.empty() ? "could not copy the dataset to device " + std::to_string(device) : err);
+        return r;
+    }
     frdev::DeviceDataset& device() { return *device_ptr(); }
+    frdev::DeviceDataset& device(int slot, int dev_ordinal) { return *device_ptr(slot, dev_ordinal); }
     const frdev::HostCSR& host_csr() {
         std::lock_guard<std::mutex> lk(mu);
         build_csr();
@@ -729,6 +770,7 @@ struct TrainStats {
     uint64_t line_searches = 0;  // batched line searches submitted (one per tick in lock step, one per set and tick when pipelined)
     uint64_t audit_values = 0, audit_mismatches = 0;  // FR_VERIFY_AUDIT=1 (see include/fastrank.h)
     uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone after a tick with > 25 % redone pairs
+    uint32_t devices = 1;      // devices train_model spread the restarts over (ticks = the longest device's)
 };
 
 // adds the exact-only line searches of a scope to the trainer's statistics (also when the scope unwinds)
@@ -811,12 +853,14 @@ struct QueryShard {
 
 class CATrainer {
   public:
+    // slot / device: which device-side copy of the view this trainer runs on (DatasetView::device_ptr(slot, device);
+    // slot 0 = the view's first device form).  train_model gives every device its own trainer and restart range.
     CATrainer(std::shared_ptr<DatasetView> view, Evaluator ev, const CAParams& p, uint32_t rbegin, uint32_t rend,
-              QueryShard shard = QueryShard())
-        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features), shard_(std::move(shard)) {
+              QueryShard shard = QueryShard(), int slot = 0, int device = -1)
+        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features), shard_(std::move(shard)), slot_(slot), device_(device) {
         if (fids_.empty()) fail_str("assertion failed: data.n_dim() > 0");
         if (view_->instances.empty()) fail_str("assertion failed: !data.instances().is_empty()");
-        frdev::DeviceDataset& dev = view_->device();
+        frdev::DeviceDataset& dev = view_->device(slot_, device_);
         d_ = dev.d();
         model_dim_ = *std::max_element(fids_.begin(), fids_.end()) + 1;  // :93-98
         if (model_dim_ > d_) fail_str("feature id out of range for this dataset");
@@ -895,7 +939,7 @@ class CATrainer {
 
     // One lock-step tick.  Returns false when every restart had already converged.
     bool tick() {
-        frdev::DeviceDataset& dev = view_->device();
+        frdev::DeviceDataset& dev = view_->device(slot_, device_);
         ExactTickCount etc_(dev, stats_);
         size_t gen_B = 0;
         if (!build_groups(-1, groups_, &gen_B)) return false;
@@ -952,7 +996,7 @@ class CATrainer {
             if (ticks_done) *ticks_done = n;
             return alive;
         }
-        frdev::DeviceDataset& dev = view_->device();
+        frdev::DeviceDataset& dev = view_->device(slot_, device_);
         ExactTickCount etc_(dev, stats_);
         constexpr int MAXP = frdev::DeviceDataset::LINESEARCH_CONTEXTS;
         uint64_t steps[MAXP] = {};
@@ -1122,7 +1166,7 @@ class CATrainer {
 
     // Replays coordinate_ascent.rs:145-186 over the batched results of the half's line searches.
     void apply_results(int part, const std::vector<double>& means) {
-        frdev::DeviceDataset& dev = view_->device();
+        frdev::DeviceDataset& dev = view_->device(slot_, device_);
         for (size_t k = 0; k < rs_.size(); k++) {
             Restart& r = rs_[k];
             if (r.done || !in_part(k, part)) continue;
@@ -1194,7 +1238,7 @@ class CATrainer {
   private:
     // Exact resident sums for the given restarts: score_linear (ordered f64 sums of best_w) -> slot.
     void refresh_resident(const std::vector<size_t>& which) {
-        frdev::DeviceDataset& dev = view_->device();
+        frdev::DeviceDataset& dev = view_->device(slot_, device_);
         const std::vector<double>& X = dev.column_absmax();
         const size_t ld = (dev.n() + 63) / 64 * 64;
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(512, (size_t(2) << 30) / (ld * sizeof(double))));
@@ -1261,6 +1305,7 @@ class CATrainer {
     uint32_t model_dim_ = 0;
     bool fused_ = false;
     bool fullrank_ = false;
+    int slot_ = 0, device_ = -1;
     bool resident_ = false;
     uint64_t res_owner_ = 0;
     uint32_t res_refresh_ = 256;  // incremental updates of a resident sum between exact refreshes

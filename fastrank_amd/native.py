@@ -240,6 +240,11 @@ def select_model(restarts: List[Dict], output_ensemble: bool = False) -> CModel:
     return CModel(_unwrap(_load().fr_select_model(payload, 1 if output_ensemble else 0)))
 
 
+def device_plan(devices: str, device_count: int, num_restarts: int, primary_device: int = 0) -> Dict:
+    """How the library's own train_model would spread a request over the devices of FR_DEVICES=`devices` (no device needed)."""
+    return _json_reply(_load().fr_debug_device_plan(devices.encode("utf-8"), device_count, num_restarts, primary_device))
+
+
 def shard_bounds(num_restarts: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block partition of restart ids over ranks (first ranks take the remainder)."""
     base, rem = divmod(num_restarts, world)

@@ -202,6 +202,13 @@ int fr_synchronize(void);
  * 2: the term a candidate key's error bound gains from the resident form (a = bound, b = norm, c = T).
  * No device needed.  NaN for an unknown `which`. */
 double fr_debug_resident_bound(int which, double a, double b, double c);
+/* How train_model spreads `num_restarts` coordinate-ascent restarts over the devices listed in `devices_csv` (the syntax
+ * of the FR_DEVICES environment variable: comma-separated ordinals, the same ordinal twice = two contexts on that
+ * device) on a node with `device_count` devices, when the dataset's first device form lives on `primary_device`:
+ * JSON {"devices": [...], "slots": [...], "blocks": [[begin, end], ...]} -- contiguous blocks of restart ids, the first
+ * devices take the remainder (the reference fans restarts out with rayon, src/coordinate_ascent.rs:215-225).  No device
+ * needed; errors come back in the usual envelope. */
+const void *fr_debug_device_plan(const void *devices_csv, int device_count, uint32_t num_restarts, int primary_device);
 
 #ifdef __cplusplus
 }

@@ -227,6 +227,26 @@ def test_shard_bounds_cover_all_restarts():
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
 
 
+def test_in_process_device_plan_partitions_like_the_multi_process_path():
+    """train_model's fan-out over the GPUs of a node (FR_DEVICES): contiguous restart blocks, identical to
+    native.shard_bounds; the device that already holds the dataset keeps it (slot 0), every other entry gets a
+    device-to-device copy; never more devices than restarts; the same ordinal twice = two contexts."""
+    for devices, count, R in (("0,1,2,3,4,5,6,7", 8, 256), ("0,1,2", 8, 32), ("0,0", 1, 32), ("3,1", 4, 5), ("0,1,2,3", 4, 2), ("2", 4, 7)):
+        pl = native.device_plan(devices, count, R, primary_device=0)
+        want = [int(x) for x in devices.split(",")][:max(1, min(R, len(devices.split(","))))]
+        assert pl["devices"] == want
+        k = len(want)
+        assert [tuple(b) for b in pl["blocks"]] == [native.shard_bounds(R, i, k) for i in range(k)]
+        assert pl["blocks"][0][0] == 0 and pl["blocks"][-1][1] == R
+        assert sorted(pl["slots"]) == (list(range(k)) if 0 in want else list(range(1, k + 1)))
+        if 0 in want:
+            assert pl["slots"][want.index(0)] == 0  # the first listing of the primary's device reuses the primary
+    assert native.device_plan("0,0", 1, 32)["slots"] == [0, 1]
+    for bad, msg in (("0,9", "no device 9"), ("a,b", "not a list"), ("", "empty"), (",,", "empty")):
+        with pytest.raises(Exception, match=msg):
+            native.device_plan(bad, 8, 32)
+
+
 def test_json_nesting_limit_like_serde():
     """serde_json stops at 128 nested containers with an error envelope; a model 200 000 levels deep must not
     take the process down (it used to overflow the stack in the recursive parser / tree conversions)."""

@@ -1,0 +1,109 @@
+"""train_model's in-process fan-out over the devices of a node (FR_DEVICES; csrc/capi.cpp train_ca_devices): the
+reference spreads a request's restarts over the host's cores inside the call (rayon, src/coordinate_ascent.rs:215-225),
+this library over GPUs.  On the one-GPU test box the same ordinal is listed twice: two independent device-side copies of
+the dataset (the second made device to device, DeviceDataset::replicate), two host threads, two trainers -- the model
+must be the one a single trainer returns, bit for bit, because a restart's trajectory depends on its child seed only."""
+import os
+
+import numpy as np
+import pytest
+
+import fastrank_amd as fr
+from fastrank_amd import native
+from oracle import pyoracle as o
+from tests.conftest import synth_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _request(measure, restarts, **kw):
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = measure
+    p = req.params
+    p.num_restarts, p.num_max_iterations, p.seed, p.quiet = restarts, 6, 42, True
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return req
+
+
+def _train(ds, req, devices):
+    old = os.environ.pop("FR_DEVICES", None)
+    try:
+        if devices is not None:
+            os.environ["FR_DEVICES"] = devices
+        model = ds.train_model(req).to_dict()
+        return model, native.last_train_stats()
+    finally:
+        os.environ.pop("FR_DEVICES", None)
+        if old is not None:
+            os.environ["FR_DEVICES"] = old
+
+
+@pytest.fixture(scope="module")
+def data():
+    X, y, qid = synth_dataset(11, 60000, 40, 500)
+    return X, y, qid, fr.CDataset.from_numpy(X, y, qid)
+
+
+@pytest.mark.parametrize("measure", ["ndcg@10", "ndcg", "map", "mrr"])
+def test_two_contexts_on_one_device_train_the_single_trainer_model(data, measure):
+    X, y, qid, g = data
+    req = _request(measure, 32)
+    one, st1 = _train(g, req, "0")
+    two, st2 = _train(g, req, "0,0")
+    assert one == two
+    assert st1["devices"] == 1 and st2["devices"] == 2
+    assert st2["restarts"] == 32 and st2["useful_evals"] == st1["useful_evals"]
+    three, st3 = _train(g, req, "0,0,0")  # 11 + 11 + 10 restarts; the copies of the earlier run are reused
+    assert three == one and st3["devices"] == 3
+
+
+def test_fan_out_matches_the_oracle_and_handles_ensembles_and_few_restarts(data):
+    X, y, qid, g = data
+    c = o.Dataset(X, y, qid)
+    o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+    try:
+        req = _request("ndcg@10", 5, output_ensemble=True)
+        got, st = _train(g, req, "0,0")
+        exp_s, exp_w, _, err = c.ca_learn("ndcg@10", req.params.to_dict(), threads=5)
+        assert err == 0 and st["devices"] == 2
+        assert got["Ensemble"]["weights"] == exp_s.tolist()  # src/coordinate_ascent.rs:232-242, in restart order
+        for k, member in enumerate(got["Ensemble"]["models"]):
+            w = exp_w[k] / np.abs(exp_w[k]).sum() if np.abs(exp_w[k]).sum() > 0 else exp_w[k]
+            assert member["Linear"]["weights"] == w.tolist()
+        # more devices than restarts: only as many trainers as restarts
+        req1 = _request("ndcg@10", 1)
+        got1, st1 = _train(g, req1, "0,0,0,0")
+        assert st1["devices"] == 1
+        s1, w1, _, _ = c.ca_learn("ndcg@10", req1.params.to_dict())
+        assert got1 == {"Linear": {"weights": w1[0].tolist()}}
+        # last maximum over the GATHERED history, not per device
+        req2 = _request("ndcg@10", 6)
+        got2, _ = _train(g, req2, "0,0,0")
+        s2, w2, _, _ = c.ca_learn("ndcg@10", req2.params.to_dict(), threads=6)
+        assert got2 == {"Linear": {"weights": w2[o.select_best(s2)].tolist()}}
+    finally:
+        o.set_mean_segment(0)
+
+
+def test_sampled_views_are_replicated_as_views(data):
+    X, y, qid, g = data
+    qs = sorted(set(qid.tolist()))
+    view = g.subsample_queries([str(q) for q in qs[::3]])
+    fview = view.subsample_feature_names([str(f) for f in range(0, 40, 2)])
+    for v in (view, fview):
+        req = _request("ndcg@10", 8)
+        one, _ = _train(v, req, "0")
+        two, st = _train(v, req, "0,0")
+        assert one == two and st["devices"] == 2
+    info = native.device_info(view)
+    assert info["shares_parent_matrix"]
+
+
+def test_bad_device_lists_are_errors_not_crashes(data):
+    X, y, qid, g = data
+    req = _request("ndcg@10", 4)
+    for bad in ("0,99", "x", ","):
+        with pytest.raises(Exception, match="FR_DEVICES"):
+            _train(g, req, bad)
+    assert _train(g, req, "0")[0] == _train(g, req, None)[0]
