@@ -1123,7 +1123,7 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
                 }
             if (out_per_query) fr::fail_str("fr_evaluate_candidates: per-query output is not available on the general sort path");
             std::vector<double> means;
-            fr::evaluate_means_generic(view, ev, w, slot.size(), means);
+            fr::evaluate_means_generic(view.device(), ev, w, slot.size(), means);
             for (size_t g = 0; g < n_groups * 64; g++) out_means[g] = 0.0;
             for (size_t k = 0; k < slot.size(); k++) out_means[slot[k]] = means[k];
         }

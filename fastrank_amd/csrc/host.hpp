@@ -821,9 +821,8 @@ inline void line_candidates(double orig, const CAParams& p, std::vector<double>&
 }
 
 // Batched evaluate_mean of arbitrary weight vectors through the general sort path.
-inline void evaluate_means_generic(DatasetView& view, const Evaluator& ev, const std::vector<double>& weights,
+inline void evaluate_means_generic(frdev::DeviceDataset& dev, const Evaluator& ev, const std::vector<double>& weights,
                                    size_t B, std::vector<double>& means) {
-    frdev::DeviceDataset& dev = view.device();
     const size_t d = dev.d();
     means.assign(B, 0.0);
     // bound the score scratch to ~2 GiB
@@ -903,7 +902,7 @@ class CATrainer {
         }
         std::vector<double> means;
         dev.set_sums_only((bool)shard_.allreduce);
-        evaluate_means_generic(*view_, ev_, w0, R, means);
+        evaluate_means_generic(dev, ev_, w0, R, means);
         global_means(means);
         for (size_t k = 0; k < R; k++) {
             if (means[k] != means[k]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
@@ -965,7 +964,7 @@ class CATrainer {
             stats_.verify_redone += r1 - r0;
             check_flags(dev);
         } else {
-            evaluate_means_generic(*view_, ev_, gen_w_, gen_B, means_);
+            evaluate_means_generic(dev, ev_, gen_w_, gen_B, means_);
         }
         global_means(means_);
         stats_.ticks++;

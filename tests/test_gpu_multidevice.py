@@ -69,7 +69,10 @@ def test_fan_out_matches_the_oracle_and_handles_ensembles_and_few_restarts(data)
         assert err == 0 and st["devices"] == 2
         assert got["Ensemble"]["weights"] == exp_s.tolist()  # src/coordinate_ascent.rs:232-242, in restart order
         for k, member in enumerate(got["Ensemble"]["models"]):
-            w = exp_w[k] / np.abs(exp_w[k]).sum() if np.abs(exp_w[k]).sum() > 0 else exp_w[k]
+            norm = 0.0  # l1_normalize sums |w_j| sequentially (src/coordinate_ascent.rs:72-82); numpy's sum is pairwise
+            for v in exp_w[k]:
+                norm += abs(float(v))
+            w = exp_w[k] / norm if norm > 0 else exp_w[k]
             assert member["Linear"]["weights"] == w.tolist()
         # more devices than restarts: only as many trainers as restarts
         req1 = _request("ndcg@10", 1)
