@@ -259,6 +259,10 @@ def main():
     ap.add_argument("--steal-block", type=int, default=0,
                     help="e2e leg: ranks pull blocks of this many restarts from a shared counter (0 = static block partition)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the train-to-convergence leg")
+    ap.add_argument("--inprocess-devices", default=os.environ.get("FR_BENCH_INPROCESS", ""),
+                    help="single process only: also train the e2e job through the library's own train_model with FR_DEVICES set "
+                         "to this list (e.g. 0,1,2,3,4,5,6,7, or 0,0 for two contexts on one GPU): the in-process fan-out a caller "
+                         "of the reference's API gets, next to the one-process-per-GPU numbers")
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -458,6 +462,32 @@ def main():
     else:
         e2e_top = None
 
+    # ---- optional third leg: the same job through train_model itself, fanned out inside the library over FR_DEVICES ----
+    inproc = None
+    if args.inprocess_devices and world == 1:
+        p.seed = 42
+        old_env = os.environ.get("FR_DEVICES")
+        os.environ["FR_DEVICES"] = args.inprocess_devices
+        try:
+            runs = []
+            for attempt in range(2):  # the first call also makes the device-to-device copies of the dataset
+                t0 = time.perf_counter()
+                m2 = dataset.train_model(req)
+                wall = time.perf_counter() - t0
+                st = native.last_train_stats()
+                runs.append({"wall_s": wall, "useful_evals": st["useful_evals"], "e2e_evals_per_s": st["useful_evals"] / wall,
+                             "devices": st["devices"], "ticks_longest_device": st["ticks"]})
+            sha = hashlib.sha1(json.dumps(m2.to_dict(), sort_keys=True).encode()).hexdigest()
+            inproc = {"what": "dataset.train_model(request) with FR_DEVICES={}: restarts block-partitioned over the listed devices "
+                              "inside the call, one host thread + trainer + device-to-device dataset copy each".format(args.inprocess_devices),
+                      "first_call_with_replication": runs[0], "second_call": runs[1], "model_sha1": sha,
+                      "same_model_as_e2e_leg": (e2e is not None and sha == e2e["model_sha1"]) if e2e is not None else None}
+        finally:
+            if old_env is None:
+                del os.environ["FR_DEVICES"]
+            else:
+                os.environ["FR_DEVICES"] = old_env
+
     if rank == 0:
         b_eval = n * (4 * d + 8)  # algorithmic bytes per evaluate_mean
         # dominant kernel: the bound-and-verify line search (the exact kernels only recompute the pairs it
@@ -622,6 +652,7 @@ def main():
                                       "note": "HIP-event durations of the timed launches; three are in flight, so they overlap"},
             "kernels_ms": {k: v["total_ms"] for k, v in prof.items()},
             "e2e": e2e,
+            "inprocess": inproc,
             "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "best_score_so_far": best_so_far},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -184,6 +184,9 @@ class DeviceDataset {
     struct RfActive { uint32_t tree, key, n; };
     struct RfCand { double position, importance; uint32_t ids_i, flags, pos_l, pos_r; };
     struct RfSplit { int32_t fslot; uint32_t pos, left, right; };
+    // File-loaded datasets: bit f of bits_by_instance[id * words + f / 32] = instance id HOLDS feature f (the reference's
+    // FeatureStats skips absent values, src/normalizers.rs:24-29, while the sort reads them as 0.0).  nullptr: all held.
+    bool rf_set_presence(const uint32_t* bits_by_instance, size_t words, size_t n_instances, std::string* err);
     bool rf_begin(const std::vector<uint32_t>& root_off, const std::vector<uint32_t>& root_ids, uint32_t nf,
                   const std::vector<uint32_t>& feats, std::string* err);
     // compute_output of every tree's whole sample (random_forest.rs:344-351: a root that does not split)

@@ -335,6 +335,12 @@ struct DataCore {
     std::vector<uint32_t> features;   // feature ids present (ascending)
     std::map<uint32_t, std::string> feature_names;
     bool is_dense_borrowed = false;
+    // File-loaded datasets: which features each instance HOLDS (src/instance.rs:64-74: a Dense32 row holds every index
+    // below its length, a Sparse32 row the listed ones).  An absent value reads 0.0 wherever a value is needed, but
+    // FeatureStats skips it (src/normalizers.rs:24-29) -- random-forest training needs the difference.  Bits
+    // [n][present_words] (feature f: word f / 32, bit f % 32); empty when every instance holds every feature.
+    std::vector<uint32_t> present_bits;
+    size_t present_words = 0;
     // One device job at a time per DATASET (every view of a core shares its device forms and their work buffers);
     // calls on different datasets run concurrently -- each on the devices it was given.
     std::mutex api_mu;

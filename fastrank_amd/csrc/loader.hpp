@@ -208,6 +208,26 @@ inline std::shared_ptr<DatasetView> load_ranksvm(const std::string& path,
     for (size_t i = 0; i < rows.size(); i++)
         for (const auto& fv : rows[i].feats) core->x_own[i * core->d + fv.first] = fv.second;
     core->x = core->x_own.data();
+    {
+        // which features every row holds (see DataCore::present_bits); kept only if some row lacks some feature
+        const size_t pw = (core->d + 31) / 32;
+        std::vector<uint32_t> bits(core->n * pw, 0u);
+        bool any_absent = false;
+        for (size_t i = 0; i < rows.size(); i++) {
+            uint32_t* b = bits.data() + i * pw;
+            size_t held = 0;
+            if (rows[i].dense_len > 0) {
+                for (uint32_t j = 0; j < rows[i].dense_len && j < core->d; j++) b[j >> 5] |= 1u << (j & 31), held++;
+            } else {
+                for (const auto& fv : rows[i].feats) b[fv.first >> 5] |= 1u << (fv.first & 31), held++;
+            }
+            any_absent = any_absent || held != core->d;
+        }
+        if (any_absent) {
+            core->present_bits = std::move(bits);
+            core->present_words = pw;
+        }
+    }
     core->has_docids = any_docid;
     if (names) core->feature_names = *names;
     auto view = std::make_shared<DatasetView>();

@@ -123,6 +123,10 @@ class RFTrainer {
         std::vector<std::vector<uint32_t>> qids_sorted;  // built lazily per query
         qids_sorted.resize(csr.nq);
 
+        {
+            std::string perr;
+            if (!dev.rf_set_presence(core.present_bits.empty() ? nullptr : core.present_bits.data(), core.present_words, core.n, &perr)) fail_str(perr);
+        }
         Rand64 rand(p_.seed);
         std::vector<uint64_t> seeds(p_.num_trees);
         for (uint32_t t = 0; t < p_.num_trees; t++) seeds[t] = rand.rand_u64();

@@ -116,6 +116,9 @@ typedef struct {
     size_t n, d;
     const float *x;   /* row-major n x d, borrowed (src/lib.rs:224-240) */
     const double *y;  /* labels, borrowed */
+    const uint8_t *present; /* optional [n*d], borrowed: 0 = the instance does not HOLD that feature (file-loaded rows,
+                               src/instance.rs:64-74); it then reads 0.0 where a value is needed (unwrap_or(0.0)) and is
+                               skipped by FeatureStats (src/normalizers.rs:24-29).  NULL: every value is present */
     size_t nq;
     uint32_t *qid;    /* [nq] query ids in first-appearance order */
     size_t *qoff;     /* [nq+1] */
@@ -198,6 +201,9 @@ oracle_dataset *oracle_dataset_new(size_t n, size_t d, const float *x, const dou
     free(p);
     return ds;
 }
+
+/* presence mask of a file-loaded dataset (see oracle_dataset.present); the caller keeps the array alive */
+void oracle_dataset_set_presence(oracle_dataset *ds, const uint8_t *present) { ds->present = present; }
 
 void oracle_dataset_free(oracle_dataset *ds) {
     if (!ds) return;
@@ -992,16 +998,22 @@ static int32_t rf_learn_recursive(const oracle_dataset *ds, const oracle_rf_para
     uint32_t best_fid = 0;
     for (size_t fi = 0; fi < nf; fi++) {
         const uint32_t f = fids[fi];
-        /* FeatureStats (normalizers.rs:13-37): min / max over the node's instances; > 1 element (stats.rs:98-103) */
+        /* FeatureStats (normalizers.rs:13-37): min / max over the values the node's instances HOLD (absent ones are
+           skipped, :24-29); a feature with fewer than two such values has no stats (stats.rs:98-103) and yields no
+           candidate (random_forest.rs:383-386).  The sort below reads 0.0 for an absent value (:228). */
         double fmin = 1.7976931348623157e308, fmax = -1.7976931348623157e308;
+        size_t held = 0;
         for (size_t i = 0; i < n; i++) {
             double v = (double)ds->x[(size_t)ids[i] * ds->d + f];
             keys[i].v = v;
             keys[i].pos = ridx[i];
             keys[i].id = ids[i];
+            if (ds->present && !ds->present[(size_t)ids[i] * ds->d + f]) continue;
+            held++;
             if (fmax < v) fmax = v;
             if (fmin > v) fmin = v;
         }
+        if (held <= 1) continue;
         const double range = fmax - fmin;
         qsort(keys, n, sizeof(rf_key), cmp_rf_key); /* random_forest.rs:225-233 */
         for (size_t i = 0; i < n; i++) sorted[i] = keys[i].id, sorted_r[i] = keys[i].pos;

@@ -67,6 +67,7 @@ def lib():
     L.oracle_dataset_new.restype = vp
     L.oracle_dataset_new.argtypes = [sz, sz, vp, vp, vp]
     L.oracle_dataset_free.argtypes = [vp]
+    L.oracle_dataset_set_presence.argtypes = [vp, vp]
     L.oracle_num_queries.restype = sz
     L.oracle_num_queries.argtypes = [vp]
     L.oracle_query_ids.argtypes = [vp, vp]
@@ -144,6 +145,18 @@ class Dataset:
         if getattr(self, "ptr", None):
             lib().oracle_dataset_free(self.ptr)
             self.ptr = None
+
+    def set_presence(self, present):
+        """File-loaded datasets (src/instance.rs:64-74): present[i, f] = False where instance i does not HOLD feature f
+        (it reads 0.0 where a value is needed, and FeatureStats skips it: src/normalizers.rs:24-29).  None = all held."""
+        if present is None:
+            self._present = None
+            lib().oracle_dataset_set_presence(self.ptr, None)
+            return
+        pm = np.ascontiguousarray(present, dtype=np.uint8)
+        assert pm.shape == (self.n, self.d)
+        self._present = pm  # (borrowed by the C side)
+        lib().oracle_dataset_set_presence(self.ptr, _p(pm))
 
     def query_ids(self):
         out = np.zeros(self.nq, dtype=np.uint32)

@@ -68,3 +68,24 @@ def synth_dataset(seed, n, d, q, max_len=None):
             col = col + 0.3 * y
         X[:, j] = col.astype(np.float32)
     return X, y, qid
+
+
+def ranksvm_presence(path, d):
+    """present[i, f] for a ranksvm / libsvm file as the reference holds it (src/instance.rs:104-130): a row whose listed
+    features cover at least half of 1..max index becomes Dense32 of length max + 1 and HOLDS every index below that
+    (unlisted ones as 0.0); a sparser row holds exactly what it lists.  Independent of the product's loader."""
+    rows = []
+    with open(path) as fh:
+        for line in fh:
+            data = line.split("#", 1)[0].split()
+            if not data:
+                continue
+            ids = [int(tok.split(":", 1)[0]) for tok in data[1:] if not tok.startswith("qid:")]
+            mx = max(ids) if ids else 1
+            held = np.zeros(d, dtype=bool)
+            if len(ids) / mx >= 0.5:
+                held[: mx + 1] = True
+            else:
+                held[ids] = True
+            rows.append(held)
+    return np.array(rows)

@@ -10,7 +10,7 @@ import pytest
 import fastrank_amd as fr
 from fastrank_amd import native
 from oracle import pyoracle as o
-from tests.conftest import GOLDEN, synth_dataset
+from tests.conftest import GOLDEN, ranksvm_presence, synth_dataset
 
 pytestmark = pytest.mark.gpu
 
@@ -153,3 +153,28 @@ def test_degenerate_nodes_become_leaves():
     g1, c1 = fr.CDataset.from_numpy(X, y1, qid), o.Dataset(X, y1, qid)
     req = _request("ndcg", num_trees=2, seed=3, min_leaf_support=1)
     assert g1.train_model(req).to_dict() == _oracle(c1, req)[0]
+
+
+@pytest.mark.parametrize("method", ["SquaredError", "TrueVarianceReduction"])
+def test_file_loaded_dataset_feature_stats_skip_absent_values(method):
+    """examples/trec_news_2018.train as the reference loads it: 13 rows do not HOLD feature 5 (Dense32 of length 5).  An
+    absent value sorts as 0.0 (src/random_forest.rs:228) but FeatureStats -- the min / max the k-1 thresholds are spread
+    over -- skips it (src/normalizers.rs:24-29).  Round 2 densified the file and took min / max over the zeros too."""
+    path = os.path.join(GOLDEN, "data", "trec_news_2018.train")
+    rd = fr.CDataset.open_ranksvm(path)
+    d = np.load(os.path.join(GOLDEN, "trec_news_2018.npz"))
+    X, y, qid = d["train_X"], d["train_y"], d["train_qid"]
+    present = ranksvm_presence(path, X.shape[1])
+    assert present.shape == X.shape and int((~present).sum()) > 0 and not X[~present].any()
+    c = o.Dataset(X, y, qid)
+    c.set_presence(present)
+    req = _request(num_trees=10, seed=42, split_candidates=32, max_depth=10, min_leaf_support=2, split_method=method,
+                   instance_sampling_rate=1.0, feature_sampling_rate=1.0)
+    got = rd.train_model(req).to_dict()
+    exp, _ = _oracle(c, req)
+    assert got == exp
+    # the same file as a numpy DenseDataset holds every value (src/dense_dataset.rs:143-147): different thresholds
+    c.set_presence(None)
+    dense_exp, _ = _oracle(c, req)
+    assert fr.CDataset.from_numpy(X, y, qid).train_model(req).to_dict() == dense_exp
+    assert dense_exp != exp
