@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Sampled views at the 30K shape: HBM owned by an 80 % query sample, time to its first compute call,
-and NDCG@10 training throughput on it -- sharing the parent's tiles (default) vs tiling its own copy (FR_VIEW_COPIES=1)."""
+"""Sampled views at the 30K shape: what a query sample of 10 / 25 / 50 / 80 / 100 % costs -- HBM it owns, time to its
+device form, trainer start-up (the restarts' exact first scores), NDCG@10 tick, one evaluate call and one forest-scoring
+pass -- each next to the same call on the whole dataset.  A view shares its parent's tiles and visits only the tiles that
+hold its documents (DeviceDataset::create_view, PosMap), so every column should scale with the sample.
+FR_VIEW_ALL_TILES=1 gives round 2's behaviour (position-parallel kernels visit every parent position) for comparison."""
 import json
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,39 +18,61 @@ import fastrank_amd as fr  # noqa: E402
 from fastrank_amd import native  # noqa: E402
 
 
+def timed(fn, reps=3):
+    fn()
+    native.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    native.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def measure(ds, n_total, forest, linear):
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    req.params.num_restarts, req.params.quiet, req.params.seed = 32, True, 42
+    t0 = time.perf_counter()
+    info = native.device_info(ds)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    run = native.CoordinateAscentRun(ds, req)
+    native.synchronize()
+    t_init = time.perf_counter() - t0
+    run.step(5)
+    native.synchronize()
+    t0 = time.perf_counter()
+    run.step(40)
+    native.synchronize()
+    tick = (time.perf_counter() - t0) / 40
+    run.close()
+    return {"hbm_bytes_owned": info["hbm_bytes_owned"], "queries": info["queries"], "instances": info["instances"],
+            "device_form_s": t_dev, "trainer_init_s": t_init, "ms_per_tick": tick * 1e3,
+            "evaluate_ndcg10_ms": timed(lambda: native.evaluate_dense(linear, ds, "ndcg@10")) * 1e3,
+            "forest_100_trees_pass_ms": timed(lambda: native.predict_scores_dense(forest, ds, 0)) * 1e3}
+
+
 def main():
     n, d, q, seed = bench.SHAPES["30k"]
     X, y, qid = bench.gen_mslr_shaped(seed, n, d, q)
     parent = fr.CDataset.from_numpy(X, y, qid)
-    pinfo = native.device_info(parent)
+    rng = np.random.default_rng(7)
+    trees = bench.random_trees(rng, X, 100, 8)
+    forest = fr.CModel.from_dict({"Ensemble": {"weights": [1.0] * len(trees), "models": [{"DecisionTree": t} for t in trees]}})
+    w = rng.uniform(-1, 1, d)
+    linear = fr.CModel.from_dict({"Linear": {"weights": (w / np.abs(w).sum()).tolist()}})
     names = [str(v) for v in range(1, q + 1)]
-    train = [s for i, s in enumerate(names) if i % 5 != 0]
-    out = {"parent_hbm_bytes": pinfo["hbm_bytes_owned"], "view": "4 of every 5 queries (%d)" % len(train)}
-    for mode in ("shared", "copy"):
-        if mode == "copy":
-            os.environ["FR_VIEW_COPIES"] = "1"
-        t0 = time.perf_counter()
-        view = parent.subsample_queries(train)
-        t_sample = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        info = native.device_info(view)
-        t_dev = time.perf_counter() - t0
-        req = fr.TrainRequest.coordinate_ascent()
-        req.measure = "ndcg@10"
-        req.params.num_restarts, req.params.quiet, req.params.seed = 32, True, 42
-        run = native.CoordinateAscentRun(view, req)
-        run.step(5)
-        native.synchronize()
-        t0 = time.perf_counter()
-        run.step(40)
-        native.synchronize()
-        dt = time.perf_counter() - t0
-        st = run.state()["stats"]
-        out[mode] = {"hbm_bytes_owned": info["hbm_bytes_owned"], "shares_parent_matrix": info["shares_parent_matrix"],
-                     "host_sampling_s": t_sample, "device_form_s": t_dev, "ms_per_tick": dt / 40 * 1e3,
-                     "raw_evals_per_s_40_ticks": 40 * 32 * 51 / dt, "path": st["path"]}
-        run.close()
+    out = {"shape": "30k", "all_tiles": bool(os.environ.get("FR_VIEW_ALL_TILES")), "rows": {}}
+    out["rows"]["100% (the dataset itself)"] = measure(parent, n, forest, linear)
+    for pct in (80, 50, 25, 10):
+        keep = rng.permutation(q)[: q * pct // 100]
+        view = parent.subsample_queries([names[i] for i in sorted(keep.tolist())])
+        out["rows"]["%d%% of the queries" % pct] = measure(view, n, forest, linear)
         del view
+    base = out["rows"]["100% (the dataset itself)"]
+    for k, r in out["rows"].items():
+        r["relative_to_whole"] = {m: r[m] / base[m] for m in ("trainer_init_s", "ms_per_tick", "evaluate_ndcg10_ms", "forest_100_trees_pass_ms")}
+        r["share_of_instances"] = r["instances"] / base["instances"]
     print(json.dumps(out))
 
 
