@@ -365,8 +365,12 @@ def main():
 
     advance(args.warmup)
     s0 = snapshot()
+    # The timed region runs WITHOUT the library's HIP-event instrumentation (two events created and recorded around every
+    # launch: ~50 us of host time per set and tick, which is on the critical path of the pipeline -- FR_BENCH_PROFILE_TIMED=1
+    # puts it back); the per-kernel numbers come from two instrumented legs right after it, which are not part of `value`.
+    profile_timed = os.environ.get("FR_BENCH_PROFILE_TIMED", "0") == "1"
     native.profile_reset()
-    native.profile_enable(True)
+    native.profile_enable(profile_timed)
     barrier()
     t0 = time.perf_counter()
     advance(args.steps)
@@ -374,7 +378,17 @@ def main():
     elapsed = time.perf_counter() - t0
     native.profile_enable(False)
     s1 = snapshot()
-    prof = native.profile_stats()
+    if profile_timed:
+        prof, prof_steps, prof_raw = native.profile_stats(), args.steps, s1["raw_evals"] - s0["raw_evals"]
+    else:  # the same pipelined stepping, instrumented (overlapping launches: durations of the sets' kernels in flight together)
+        prof_steps = max(1, min(args.steps, 10))
+        native.profile_reset()
+        native.profile_enable(True)
+        advance(prof_steps)
+        torch.cuda.synchronize()
+        native.profile_enable(False)
+        prof = native.profile_stats()
+        prof_raw = snapshot()["raw_evals"] - s1["raw_evals"]
     # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
     # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
     # step, nothing else on the device) give the duration of an ISOLATED launch: the roofline object below is computed
@@ -496,7 +510,7 @@ def main():
                     if k in prof), "linesearch_ndcg_kernel")
         ls = prof.get(dom, {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
         exact = prof.get("linesearch_ndcg_kernel", {"launches": 0, "total_ms": 0.0, "avg_ms": 0.0})
-        evals_per_launch = (raw / max(1, ls["launches"])) if ls["launches"] else 0.0
+        evals_per_launch = (prof_raw / max(1, ls["launches"])) if ls["launches"] else 0.0
         groups_per_launch = evals_per_launch / 51.0
         step_s = elapsed_max / max(1, args.steps)
         evals_per_step = raw / max(1, args.steps)
@@ -630,7 +644,7 @@ def main():
                 "restarts_total": R,
                 "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
                 "evals_per_step_per_gpu": evals_per_step,
-                "launches_per_step": ls["launches"] / max(1, args.steps),
+                "launches_per_step": ls["launches"] / max(1, prof_steps),
                 "groups_per_launch": groups_per_launch,
                 "jobs_finished_inside_timed_region": jobs["finished"],
             },
@@ -646,11 +660,14 @@ def main():
                 "line_searches": s1["line_searches"] - s0["line_searches"],
                 # line searches evaluated by the exact kernels alone (after one with > 25 % redone pairs)
                 "exact_line_search_share": (s1["exact_ticks"] - s0["exact_ticks"]) / max(1, s1["line_searches"] - s0["line_searches"]),
-                "exact_kernel_ms_per_step": exact["total_ms"] / max(1, args.steps),
+                "exact_kernel_ms_per_step": exact["total_ms"] / max(1, prof_steps),
             },
             "per_launch_overlapped": {"avg_launch_ms": ls["avg_ms"], "launches": ls["launches"],
-                                      "note": "HIP-event durations of the timed launches; three are in flight, so they overlap"},
+                                      "note": "HIP-event durations of pipelined launches (three sets in flight, so they overlap), from {} "
+                                              "instrumented steps {}".format(prof_steps, "= the timed region" if profile_timed else "after the timed region")},
             "kernels_ms": {k: v["total_ms"] for k, v in prof.items()},
+            "instrumented_steps": prof_steps,
+            "timed_region_instrumented": profile_timed,
             "e2e": e2e,
             "inprocess": inproc,
             "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "best_score_so_far": best_so_far},
