@@ -17,9 +17,11 @@ from fastrank_amd import native  # noqa: E402
 from oracle import pyoracle as o  # noqa: E402
 
 
-def make_case(rng):
+def make_case(rng, measures=None, long_bias=False):
     nq = int(rng.integers(1, 40))
-    lens = np.maximum(1, rng.lognormal(np.log(rng.choice([3, 20, 80])), 0.8, nq).astype(int))
+    # (long_bias: query lengths spread over the full-ranking kernel's size classes -- 16 .. 96 keys per lane, 1 .. 32 lanes)
+    lens = np.maximum(1, rng.lognormal(np.log(rng.choice([3, 20, 80, 130, 250, 600] if long_bias else [3, 20, 80])), 0.8, nq).astype(int))
+    lens = np.minimum(lens, 2500)
     if rng.random() < 0.2:
         lens[rng.integers(0, nq)] = int(rng.integers(300, 2500))
     n = int(lens.sum())
@@ -50,7 +52,7 @@ def make_case(rng):
     y = rng.choice(labels, n)
     if rng.random() < 0.2:
         y[qid == qid[0]] = 0.0
-    measure = str(rng.choice(["ndcg@1", "ndcg@3", "ndcg@5", "ndcg@10", "ndcg@20", "ndcg@10", "mrr", "map", "ndcg", "ndcg@50"]))
+    measure = str(rng.choice(measures or ["ndcg@1", "ndcg@3", "ndcg@5", "ndcg@10", "ndcg@20", "ndcg@10", "mrr", "map", "ndcg", "ndcg@50"]))
     params = dict(num_restarts=int(rng.integers(1, 4)), num_max_iterations=int(rng.integers(1, 9)),
                   step_base=float(rng.choice([0.05, 0.01, 0.5])), step_scale=float(rng.choice([2.0, 1.5, 3.0])),
                   tolerance=float(rng.choice([0.001, 0.0, 0.01])), seed=int(rng.integers(0, 2 ** 31)),
@@ -62,13 +64,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--measures", default="", help="comma list to draw the measure from (default: the mixed list)")
+    ap.add_argument("--long", action="store_true", help="bias query lengths towards 100 .. 2000 documents")
     args = ap.parse_args()
+    measures = [m for m in args.measures.split(",") if m] or None
     rng = np.random.default_rng(args.seed)
     o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
     t0 = time.time()
     paths, redone, bad, sampled = {}, 0, 0, 0
     for it in range(args.iters):
-        X, y, qid, measure, params = make_case(rng)
+        X, y, qid, measure, params = make_case(rng, measures, args.long)
         g = fr.CDataset.from_numpy(X, y, qid)
         if rng.random() < 0.3 and len(np.unique(qid)) > 2:  # a query-sampled view (train/test split style)
             keep = rng.choice(np.unique(qid), size=max(1, len(np.unique(qid)) // 2), replace=False)

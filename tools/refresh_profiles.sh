@@ -58,6 +58,10 @@ done
 python tools/rfbench.py --shape 30k --trees 100 --cpu-trees 1 --check 2>&1 | tail -1 > "$OUT/${TAG}_rfbench_30k.json"
 python tools/rfbench.py --shape 10k --trees 30 --split-candidates 32 --cpu-trees 1 --check 2>&1 | tail -1 > "$OUT/${TAG}_rfbench_10k_k32.json"
 python tools/viewbench.py 2>&1 | tail -1 > "$OUT/${TAG}_views_30k.json"
+# round 3: config 5 as a bench line, the in-process fan-out (two contexts on the one GPU of this box), NDCG with a depth beyond 20
+python bench.py --measure trees --steps 20 --warmup 3 2> "$OUT/bench_trees.err" | tail -1 > "$OUT/${TAG}_bench_trees.json"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --inprocess-devices 0,0 2> "$OUT/bench_inproc.err" | tail -1 > "$OUT/${TAG}_bench_inprocess_2ctx_1gpu.json"
+{ for m in ndcg@50 ndcg@100; do python tools/train_e2e.py --measure $m --shape 30k --restarts 32 --max-ticks 136 2>&1 | tail -1; done; } > "$OUT/${TAG}_train_ndcg_cut_30k.json"
 FR_UPLOAD_TIMING=1 python tools/train_e2e.py --shape 30k --restarts 32 --max-ticks 3 2>&1 | grep "upload\]" > "$OUT/${TAG}_upload_stages.txt"
 python tools/train_e2e.py 2>&1 | tail -1 > "$OUT/${TAG}_train_e2e_10k.json"
 python tools/train_e2e.py --measure mrr --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1 > "$OUT/${TAG}_train_mrr_30k.json"
