@@ -370,9 +370,36 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
         std::string err;
         if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
     }
-    const DevicePlan pl = plan_devices(devs, R, view->device_ptr()->device_ordinal());
+    // The copies are made one after the other (they all read the first device's HBM), the training runs concurrently.
+    // A device the dataset cannot be copied to is an error when FR_DEVICES named it; of the default "every visible
+    // device" it is simply left out (the request then trains on the devices that took a copy).
+    const bool explicit_list = std::getenv("FR_DEVICES") != nullptr;
+    const int primary_dev = view->device_ptr()->device_ordinal();
+    DevicePlan pl;
+    for (;;) {
+        pl = plan_devices(devs, R, primary_dev);
+        std::vector<int> kept;
+        std::exception_ptr first_error;
+        for (size_t i = 0; i < pl.devs.size(); i++) {
+            try {
+                (void)view->device_ptr(pl.slot[i], pl.devs[i]);
+                kept.push_back(pl.devs[i]);
+            } catch (...) {
+                if (!first_error) first_error = std::current_exception();
+            }
+        }
+        if (!first_error) break;
+        if (explicit_list || kept.empty()) std::rethrow_exception(first_error);
+        devs = kept;
+        if (devs.size() <= 1) {
+            std::string err;
+            if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
+            return train_ca(view, rq, 0, R, nullptr);
+        }
+    }
     const size_t k = pl.devs.size();
     const std::vector<int>& slot = pl.slot;
+    devs = pl.devs;
     std::vector<std::vector<fr::RestartResult>> parts(k);
     std::vector<fr::TrainStats> stats(k);
     std::vector<std::exception_ptr> errors(k);
@@ -386,16 +413,6 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
             errors[i] = std::current_exception();
         }
     };
-    // the copies are made one after the other (they all read the first device's HBM), the training runs concurrently
-    for (size_t i = 0; i < k; i++) {
-        try {
-            (void)view->device_ptr(slot[i], devs[i]);
-        } catch (...) {
-            errors[i] = std::current_exception();
-        }
-    }
-    for (size_t i = 0; i < k; i++)
-        if (errors[i]) std::rethrow_exception(errors[i]);
     std::vector<std::thread> pool;
     for (size_t i = 1; i < k; i++) pool.emplace_back(work, i);
     work(0);
