@@ -91,6 +91,7 @@ def _load():
         "fr_debug_resident_bound": (C.c_double, [C.c_int, C.c_double, C.c_double, C.c_double]),
         "fr_synchronize": (C.c_int, []),
         "fr_debug_device_plan": (vp, [C.c_char_p, C.c_int, C.c_uint32, C.c_int]),
+        "fr_debug_fullrank_class": (C.c_uint32, [C.c_uint32]),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(L, name)

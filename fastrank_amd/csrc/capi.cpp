@@ -826,6 +826,13 @@ int fr_device_count(void) { return frdev::device_count(nullptr); }
 // How train_model would spread `num_restarts` restarts over the devices of `devices_csv` (the FR_DEVICES syntax) on a
 // node with `device_count` devices whose first device form lives on `primary_device`: {"devices","slots","blocks"}.
 // No device is touched (the CPU tests check the partition and the list parsing with it).
+// keys per lane << 16 | lanes per candidate of the full-ranking kernel's size class for a query of `len` documents
+uint32_t fr_debug_fullrank_class(uint32_t len) {
+    uint32_t nl = 0, pl = 0;
+    frdev::fullrank_class_of(len, &nl, &pl);
+    return (nl << 16) | pl;
+}
+
 const void* fr_debug_device_plan(const void* devices_csv, int device_count, uint32_t num_restarts, int primary_device) {
     return json_call([&]() {
         const std::string csv = accept_str("devices_csv", devices_csv);

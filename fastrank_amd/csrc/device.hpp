@@ -220,6 +220,9 @@ void profile_enable(bool on);
 void profile_reset();
 std::vector<KernelStat> profile_stats();
 bool device_synchronize(std::string* err);
-size_t device_free_bytes();  // free HBM on the current device (0 if unknown)
+size_t device_free_bytes();
+// size class of the full-ranking kernel a query of `len` documents is sorted in: *nl keys per lane, *pl lanes per candidate
+// (no device needed; fullverify.hpp FV_CLASSES)
+void fullrank_class_of(uint32_t len, uint32_t* nl, uint32_t* pl);  // free HBM on the current device (0 if unknown)
 
 }  // namespace frdev

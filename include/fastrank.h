@@ -208,6 +208,10 @@ double fr_debug_resident_bound(int which, double a, double b, double c);
  * JSON {"devices": [...], "slots": [...], "blocks": [[begin, end], ...]} -- contiguous blocks of restart ids, the first
  * devices take the remainder (the reference fans restarts out with rayon, src/coordinate_ascent.rs:215-225).  No device
  * needed; errors come back in the usual envelope. */
+/* Size class of the full-ranking bound-and-verify kernel (depth-less NDCG, MAP, NDCG@>20) for a query of `len` documents:
+ * (keys per lane << 16) | lanes per candidate.  No device needed (the CPU tests check that every length has a class that
+ * holds it and that classes grow with the length). */
+uint32_t fr_debug_fullrank_class(uint32_t len);
 const void *fr_debug_device_plan(const void *devices_csv, int device_count, uint32_t num_restarts, int primary_device);
 
 #ifdef __cplusplus

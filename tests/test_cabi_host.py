@@ -247,6 +247,24 @@ def test_in_process_device_plan_partitions_like_the_multi_process_path():
             native.device_plan(bad, 8, 32)
 
 
+def test_fullrank_size_classes_hold_every_query_length():
+    """kernels_fullverify.inc sorts a query as pl lanes of nl register-resident keys: every length up to 2048 must land in
+    a class that holds it, the padding must stay small where the documents are, and a longer query never gets a
+    smaller class."""
+    L = clib._load()
+    prev = 0
+    waste = []
+    for n in range(1, 2049):
+        v = L.fr_debug_fullrank_class(n)
+        nl, pl = v >> 16, v & 0xFFFF
+        assert nl in (16, 32, 48, 64, 80, 96) and pl in (1, 2, 4, 8, 16, 32) and nl * pl >= n, (n, nl, pl)
+        assert nl * pl >= prev
+        prev = nl * pl
+        waste.append(nl * pl / n)
+    assert max(waste[63:1536]) <= 1.34  # 64 .. 1536 documents (power-of-two classes alone would reach 2.0)
+    assert L.fr_debug_fullrank_class(65) == (80 << 16) | 1 and L.fr_debug_fullrank_class(129) == (80 << 16) | 2
+
+
 def test_json_nesting_limit_like_serde():
     """serde_json stops at 128 nested containers with an error envelope; a model 200 000 levels deep must not
     take the process down (it used to overflow the stack in the recursive parser / tree conversions)."""
