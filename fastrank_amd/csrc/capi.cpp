@@ -347,23 +347,23 @@ static DevicePlan plan_devices(std::vector<int> devs, uint32_t R, int primary_de
     return pl;
 }
 
-fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq) {
+// The device list of one train_model call over `units` independent pieces of work (restarts, trees), with the view's
+// device-side copies made: an empty / one-entry plan means "train on the current device, slot 0".
+static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& view, uint32_t units) {
     std::vector<int> devs = fr_train_devices();
-    const uint32_t R = rq.ca.num_restarts;
     // a small matrix is not worth a context on every GPU (each costs a device-to-device copy and, the first time, the
     // runtime's per-device start-up); an explicit FR_DEVICES is taken as given
     if (!std::getenv("FR_DEVICES") && view->instances.size() * (size_t)view->core->d < (size_t(1) << 23)) devs.resize(std::min<size_t>(devs.size(), 1));
-    if (devs.size() > R) devs.resize(std::max<uint32_t>(R, 1));
-    if (devs.size() <= 1) {
-        if (!devs.empty() && (std::getenv("FR_DEVICES") || g_pinned_device >= 0)) {
+    if (devs.size() > units) devs.resize(std::max<uint32_t>(units, 1));
+    auto single = [&](const std::vector<int>& d, bool pin) {
+        if (!d.empty() && pin) {
             std::string err;
-            if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
+            if (!frdev::set_device(d[0], &err)) fr::fail_str(err);
         }
-        return train_ca(view, rq, 0, R, nullptr);
-    }
-    auto t0 = std::chrono::steady_clock::now();
-    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
-    if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
+        return plan_devices(std::vector<int>(d.begin(), d.begin() + std::min<size_t>(d.size(), 1)), units, d.empty() ? -1 : d[0]);
+    };
+    if (devs.size() <= 1) return single(devs, std::getenv("FR_DEVICES") || g_pinned_device >= 0);
+    if (view->host_csr().nq == 0) return single(devs, false);  // (the trainer reports the empty dataset its own way)
     // slot 0 is the device form the view already has (or builds now, on the first listed device); every other entry of
     // the list gets the next slot
     {
@@ -375,9 +375,8 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
     // device" it is simply left out (the request then trains on the devices that took a copy).
     const bool explicit_list = std::getenv("FR_DEVICES") != nullptr;
     const int primary_dev = view->device_ptr()->device_ordinal();
-    DevicePlan pl;
     for (;;) {
-        pl = plan_devices(devs, R, primary_dev);
+        DevicePlan pl = plan_devices(devs, units, primary_dev);
         std::vector<int> kept;
         std::exception_ptr first_error;
         for (size_t i = 0; i < pl.devs.size(); i++) {
@@ -388,15 +387,20 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
                 if (!first_error) first_error = std::current_exception();
             }
         }
-        if (!first_error) break;
+        if (!first_error) return pl;
         if (explicit_list || kept.empty()) std::rethrow_exception(first_error);
         devs = kept;
-        if (devs.size() <= 1) {
-            std::string err;
-            if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
-            return train_ca(view, rq, 0, R, nullptr);
-        }
+        if (devs.size() <= 1) return single(devs, true);
     }
+}
+
+fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq) {
+    const uint32_t R = rq.ca.num_restarts;
+    auto t0 = std::chrono::steady_clock::now();
+    const DevicePlan pl = devices_for_request(view, R);
+    if (pl.devs.size() <= 1) return train_ca(view, rq, 0, R, nullptr);
+    fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
+    std::vector<int> devs;
     const size_t k = pl.devs.size();
     const std::vector<int>& slot = pl.slot;
     devs = pl.devs;
@@ -443,8 +447,17 @@ fr::Model train_rf(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     auto t0 = std::chrono::steady_clock::now();
     fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
     fr::RFTrainer trainer(view, std::move(ev), rq.rf);
-    fr::Model m = trainer.learn();
+    // the trees of a forest are independent given their seeds (random_forest.rs:301-331 grows them with rayon): spread
+    // over FR_DEVICES like a coordinate-ascent request's restarts, block i of the trees on entry i of the list
+    std::vector<fr::RFTrainer::DevicePart> parts;
+    if (rq.rf.num_trees > 0) {
+        const DevicePlan pl = devices_for_request(view, rq.rf.num_trees);
+        if (pl.devs.size() > 1)
+            for (size_t i = 0; i < pl.devs.size(); i++) parts.push_back(fr::RFTrainer::DevicePart{pl.slot[i], pl.devs[i], pl.begin[i], pl.end[i]});
+    }
+    fr::Model m = trainer.learn(std::move(parts));
     fr::TrainStats st;
+    st.devices = trainer.stats().devices;
     st.path = "random_forest";
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     st.restarts = trainer.stats().trees;

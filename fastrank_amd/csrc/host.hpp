@@ -649,8 +649,8 @@ inline void check_flags(frdev::DeviceDataset& dev) {
     } while (0)
 
 // Score `model` for every document of the view into device score slot 0.
-inline void score_model(DatasetView& view, const Model& m) {
-    frdev::DeviceDataset& dev = view.device();
+inline void score_model(DatasetView& view, const Model& m, frdev::DeviceDataset* on = nullptr) {
+    frdev::DeviceDataset& dev = on ? *on : view.device();  // (on: one of the view's device-side copies, DatasetView::device_ptr(slot, ..))
     std::string _err;
     switch (m.kind) {
         case Model::Linear: {
@@ -695,7 +695,7 @@ inline void score_model(DatasetView& view, const Model& m) {
                         if (!trees)
                             fail_str("nested mixed ensembles are not supported by the MI355X scoring path");
                     }
-                    score_model(view, mm);
+                    score_model(view, mm, &dev);
                     if (!dev.ensemble_accumulate(m.ens_weights[t], &_err)) fail_str(_err);
                 }
                 if (!dev.ensemble_finish(&_err)) fail_str(_err);

@@ -12,6 +12,8 @@
 #pragma once
 #include <chrono>
 #include <cmath>
+#include <exception>
+#include <thread>
 
 #include "host.hpp"
 
@@ -71,7 +73,7 @@ struct RFParams {  // src/random_forest.rs:127-157
 
 struct RFStats {
     double t_sample = 0, t_begin = 0, t_level = 0, t_select = 0, t_split = 0, t_weights = 0;  // host wall seconds per stage (FR_RF_TIMING)
-    uint32_t trees = 0, batches = 0, levels = 0;
+    uint32_t trees = 0, batches = 0, levels = 0, devices = 1;
     uint64_t nodes = 0, candidates = 0, sorted_items = 0;
     double seconds = 0.0;
 };
@@ -95,17 +97,29 @@ class RFTrainer {
   public:
     RFTrainer(std::shared_ptr<DatasetView> view, Evaluator ev, RFParams p) : view_(std::move(view)), ev_(std::move(ev)), p_(p) {}
 
+    // One device-side copy of the view and the trees it grows (train_model spreads a forest's trees over the GPUs of a
+    // node like a coordinate-ascent request's restarts; the reference grows them with rayon over the host's cores,
+    // random_forest.rs:301-331).  slot / device: DatasetView::device_ptr.
+    struct DevicePart {
+        int slot = 0, device = -1;
+        uint32_t t_begin = 0, t_end = 0;
+    };
+
     // random_forest.rs:288-342 learn_ensemble
-    Model learn() {
-        frdev::DeviceDataset& dev = view_->device();
+    Model learn(std::vector<DevicePart> parts = {}) {
         const frdev::HostCSR& csr = view_->host_csr();
         const DataCore& core = *view_->core;
+        if (parts.empty()) parts.push_back(DevicePart{0, -1, 0u, p_.num_trees});
+        if (!p_.quiet && parts.size() > 1) {  // (the progress table is printed in tree order: one device)
+            parts.resize(1);
+            parts[0].t_begin = 0, parts[0].t_end = p_.num_trees;
+        }
         // sampling.rs:40-48: features ascending, query-id STRINGS ascending
-        std::vector<uint32_t> features = view_->features;
-        std::sort(features.begin(), features.end());
-        std::vector<uint32_t> queries(csr.nq);  // CSR query indices, ordered by their qid string
-        for (size_t q = 0; q < csr.nq; q++) queries[q] = (uint32_t)q;
-        std::sort(queries.begin(), queries.end(), [&](uint32_t a, uint32_t b) {
+        features_ = view_->features;
+        std::sort(features_.begin(), features_.end());
+        queries_.resize(csr.nq);  // CSR query indices, ordered by their qid string
+        for (size_t q = 0; q < csr.nq; q++) queries_[q] = (uint32_t)q;
+        std::sort(queries_.begin(), queries_.end(), [&](uint32_t a, uint32_t b) {
             return core.qnames[view_->csr_query[a]] < core.qnames[view_->csr_query[b]];
         });
         // sampling.rs:49-50: max(1, (len as f64 * rate) as usize), then take(n) from a list of len items.  Rust's cast
@@ -115,21 +129,20 @@ class RFTrainer {
             const size_t c = (x != x || x <= 0.0) ? 0 : (x >= (double)len ? len : (size_t)x);
             return std::min(len, std::max<size_t>(1, c));
         };
-        const size_t n_features = sample_count(features.size(), p_.feature_sampling_rate);
-        const size_t n_queries = sample_count(queries.size(), p_.instance_sampling_rate);
-        if (features.empty()) fail_str("assertion failed: !features.is_empty()");
-        if (queries.empty()) fail_str("assertion failed: !data.queries().is_empty()");
+        n_features_ = sample_count(features_.size(), p_.feature_sampling_rate);
+        n_queries_ = sample_count(queries_.size(), p_.instance_sampling_rate);
+        if (features_.empty()) fail_str("assertion failed: !features.is_empty()");
+        if (queries_.empty()) fail_str("assertion failed: !data.queries().is_empty()");
         // instance ids of each query in ascending order (the device layout inside a query is the ranking order)
-        std::vector<std::vector<uint32_t>> qids_sorted;  // built lazily per query
-        qids_sorted.resize(csr.nq);
-
-        {
-            std::string perr;
-            if (!dev.rf_set_presence(core.present_bits.empty() ? nullptr : core.present_bits.data(), core.present_words, core.n, &perr)) fail_str(perr);
+        qids_sorted_.assign(csr.nq, std::vector<uint32_t>());
+        for (size_t qi = 0; qi < csr.nq; qi++) {
+            std::vector<uint32_t>& ids = qids_sorted_[qi];
+            ids.assign(csr.perm.begin() + csr.qoff[qi], csr.perm.begin() + csr.qoff[qi + 1]);
+            std::sort(ids.begin(), ids.end());
         }
         Rand64 rand(p_.seed);
-        std::vector<uint64_t> seeds(p_.num_trees);
-        for (uint32_t t = 0; t < p_.num_trees; t++) seeds[t] = rand.rand_u64();
+        seeds_.resize(p_.num_trees);
+        for (uint32_t t = 0; t < p_.num_trees; t++) seeds_[t] = rand.rand_u64();
 
         Model out;
         out.kind = Model::Ensemble;
@@ -137,6 +150,53 @@ class RFTrainer {
         out.ens_weights.assign(p_.num_trees, 1.0);
         if (!p_.quiet) {
             printf("-----------------------\n|%7s|%7s|%7s|\n-----------------------\n", "Tree", "Depth", ev_.name.c_str());
+        }
+        if (parts.size() == 1) {
+            learn_part(parts[0], out, stats_);
+        } else {
+            std::vector<RFStats> st(parts.size());
+            std::vector<std::exception_ptr> errors(parts.size());
+            auto work = [&](size_t i) {
+                try {
+                    learn_part(parts[i], out, st[i]);  // (disjoint slots of out.members / out.ens_weights)
+                } catch (...) {
+                    errors[i] = std::current_exception();
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t i = 1; i < parts.size(); i++) pool.emplace_back(work, i);
+            work(0);
+            for (auto& th : pool) th.join();
+            for (auto& e : errors)
+                if (e) std::rethrow_exception(e);
+            for (const RFStats& x : st) {
+                stats_.t_sample += x.t_sample, stats_.t_begin += x.t_begin, stats_.t_level += x.t_level, stats_.t_select += x.t_select;
+                stats_.t_split += x.t_split, stats_.t_weights += x.t_weights;
+                stats_.batches += x.batches, stats_.levels += x.levels, stats_.nodes += x.nodes, stats_.candidates += x.candidates;
+                stats_.sorted_items += x.sorted_items;
+            }
+        }
+        if (getenv("FR_RF_TIMING"))
+            fprintf(stderr, "[rf] sample %.2f s, begin %.2f s, levels %.2f s, select %.2f s, split %.2f s, weights %.2f s\n", stats_.t_sample,
+                    stats_.t_begin, stats_.t_level, stats_.t_select, stats_.t_split, stats_.t_weights);
+        if (!p_.quiet) printf("-----------------------\n");
+        stats_.trees = p_.num_trees;
+        stats_.devices = (uint32_t)parts.size();
+        return out;
+    }
+
+    // trees [t_begin, t_end) on one device-side copy of the view
+    void learn_part(const DevicePart& part, Model& out, RFStats& stats) {
+        if (part.device >= 0) {  // (this host thread's current device)
+            std::string derr;
+            if (!frdev::set_device(part.device, &derr)) fail_str(derr);
+        }
+        frdev::DeviceDataset& dev = view_->device(part.slot, part.device);
+        const frdev::HostCSR& csr = view_->host_csr();
+        const DataCore& core = *view_->core;
+        {
+            std::string perr;
+            if (!dev.rf_set_presence(core.present_bits.empty() ? nullptr : core.present_bits.data(), core.present_words, core.n, &perr)) fail_str(perr);
         }
         // batches sized by device memory: rf_bytes_per_item per (sampled instance x sampled feature), at most 24 GB and at
         // most 40 % of what is free right now (the sort's scratch, the candidate tables and the per-tree score buffers
@@ -151,31 +211,27 @@ class RFTrainer {
             frdev::DeviceDataset& d;
             ~EndGuard() { d.rf_end(); }
         } end_guard{dev};
-        uint32_t t0 = 0;
-        while (t0 < p_.num_trees) {
+        uint32_t t0 = part.t_begin;
+        while (t0 < part.t_end) {
             const auto ts0 = std::chrono::steady_clock::now();
             std::vector<uint32_t> root_off(1, 0), root_ids, feats;
             uint32_t t1 = t0;
-            while (t1 < p_.num_trees) {
-                Rand64 local(seeds[t1]);
-                std::vector<uint32_t> f = features, q = queries;
+            while (t1 < part.t_end) {
+                Rand64 local(seeds_[t1]);
+                std::vector<uint32_t> f = features_, q = queries_;
                 shuffle(f, local);  // randutil.rs:14-18: shuffle all, take the first n
-                f.resize(n_features);
+                f.resize(n_features_);
                 shuffle(q, local);
-                q.resize(n_queries);
+                q.resize(n_queries_);
                 std::vector<char> chosen(csr.nq, 0);
                 for (uint32_t qi : q) chosen[qi] = 1;
                 const size_t before = root_ids.size();
                 for (size_t qi = 0; qi < csr.nq; qi++) {  // sampling.rs:56-60 in the dataset's query order
                     if (!chosen[qi]) continue;
-                    std::vector<uint32_t>& ids = qids_sorted[qi];
-                    if (ids.empty()) {
-                        ids.assign(csr.perm.begin() + csr.qoff[qi], csr.perm.begin() + csr.qoff[qi + 1]);
-                        std::sort(ids.begin(), ids.end());
-                    }
+                    const std::vector<uint32_t>& ids = qids_sorted_[qi];
                     root_ids.insert(root_ids.end(), ids.begin(), ids.end());
                 }
-                const size_t items = root_ids.size() * n_features;
+                const size_t items = root_ids.size() * n_features_;
                 if (t1 > t0 && (items * dev.rf_bytes_per_item() > budget || items >= (size_t(1) << 31))) {
                     root_ids.resize(before);  // this tree opens the next batch
                     break;
@@ -185,18 +241,11 @@ class RFTrainer {
                 root_off.push_back((uint32_t)root_ids.size());
                 t1++;
             }
-            stats_.t_sample += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
-            grow_batch(dev, t0, t1, root_off, root_ids, (uint32_t)n_features, feats, out);
-            stats_.batches++;
+            stats.t_sample += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+            grow_batch(dev, t0, t1, root_off, root_ids, (uint32_t)n_features_, feats, out, stats);
+            stats.batches++;
             t0 = t1;
         }
-        dev.rf_end();
-        if (getenv("FR_RF_TIMING"))
-            fprintf(stderr, "[rf] sample %.2f s, begin %.2f s, levels %.2f s, select %.2f s, split %.2f s, weights %.2f s\n", stats_.t_sample,
-                    stats_.t_begin, stats_.t_level, stats_.t_select, stats_.t_split, stats_.t_weights);
-        if (!p_.quiet) printf("-----------------------\n");
-        stats_.trees = p_.num_trees;
-        return out;
     }
 
     const RFStats& stats() const { return stats_; }
@@ -214,7 +263,7 @@ class RFTrainer {
     static uint32_t tree_depth(const TreeNode& n) { return n.leaf ? 1 : 1 + std::max(tree_depth(*n.lhs), tree_depth(*n.rhs)); }
 
     void grow_batch(frdev::DeviceDataset& dev, uint32_t t0, uint32_t t1, const std::vector<uint32_t>& root_off,
-                    const std::vector<uint32_t>& root_ids, uint32_t nf, const std::vector<uint32_t>& feats, Model& out) {
+                    const std::vector<uint32_t>& root_ids, uint32_t nf, const std::vector<uint32_t>& feats, Model& out, RFStats& stats_) {
         const uint32_t T = t1 - t0;
         std::string err;
         auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -346,10 +395,10 @@ class RFTrainer {
             stats_.nodes += 1;
             if (p_.weight_trees || !p_.quiet) {
                 // random_forest.rs:315: the tree's evaluate_mean over the whole training dataset
-                score_model(*view_, mm);
+                score_model(*view_, mm, &dev);
                 std::string e2;
                 double mean = 0.0;
-                frdev::DeviceDataset& d2 = view_->device();
+                frdev::DeviceDataset& d2 = dev;
                 if (!d2.metric_from_scores(ev_.measure, ev_.depth, ev_.norms.data(), 1, false, &e2)) fail_str(e2);
                 if (!d2.reduce_means(1, &mean, &e2)) fail_str(e2);
                 check_flags(d2);
@@ -371,6 +420,11 @@ class RFTrainer {
     Evaluator ev_;
     RFParams p_;
     RFStats stats_;
+    // shared, read-only while the parts run
+    std::vector<uint32_t> features_, queries_;
+    size_t n_features_ = 0, n_queries_ = 0;
+    std::vector<std::vector<uint32_t>> qids_sorted_;
+    std::vector<uint64_t> seeds_;
 };
 
 }  // namespace fr

@@ -110,3 +110,23 @@ def test_bad_device_lists_are_errors_not_crashes(data):
         with pytest.raises(Exception, match="FR_DEVICES"):
             _train(g, req, bad)
     assert _train(g, req, "0")[0] == _train(g, req, None)[0]
+
+
+def test_random_forest_trees_spread_over_the_device_list(data):
+    """random_forest.rs:301-331 grows the trees in parallel, each from its own seed: block i of the trees on entry i of
+    FR_DEVICES must give the forest one device grows."""
+    X, y, qid, g = data
+    req = fr.TrainRequest.random_forest()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.num_trees, p.max_depth, p.split_candidates, p.min_leaf_support, p.seed, p.quiet = 7, 5, 8, 10, 13, True
+    p.instance_sampling_rate, p.feature_sampling_rate = 0.5, 0.5
+    one, st1 = _train(g, req, "0")
+    two, st2 = _train(g, req, "0,0")
+    three, st3 = _train(g, req, "0,0,0")
+    assert one == two == three
+    assert len(one["Ensemble"]["models"]) == 7
+    assert st1["devices"] == 1 and st2["devices"] == 2 and st3["devices"] == 3
+    assert st2["useful_evals"] == st1["useful_evals"] and st2["restarts"] == 7
+    view = g.subsample_queries([str(q) for q in sorted(set(qid.tolist()))[::2]])
+    assert _train(view, req, "0")[0] == _train(view, req, "0,0")[0]
