@@ -84,7 +84,8 @@ const CResult *make_dense_dataset_f32_f64_i64(size_t n, size_t d, const float *x
  * batched HIP launches (src/coordinate_ascent.rs:87-254); RandomForest requests are trained on the device too,
  * level-synchronously over batches of trees (src/random_forest.rs:211-408; csrc/rf_train.hpp, kernels_rf.inc).
  * With several devices visible (FR_DEVICES, default: all) the restarts of a coordinate-ascent request are spread
- * over them inside this call, like the reference's rayon fan-out over restarts (src/coordinate_ascent.rs:215-225). */
+ * over them inside this call, like the reference's rayon fan-out over restarts (src/coordinate_ascent.rs:215-225),
+ * and so are the trees of a random-forest request (src/random_forest.rs:301-331). */
 const CResult *train_model(void *train_request_json, void *dataset);
 /* src/lib.rs:258-263 */
 const CResult *model_from_json(const void *json_str);
