@@ -560,10 +560,11 @@ def main():
 
         # -- what actually binds the kernel: VALU issue.  Wave-level instruction counts are PMC constants (see `pmc`).
         def valu_block(insts_per_group, mix, groups, seconds):
-            """utilisation of the VALU issue slots: every wave instruction priced at 4 cycles (f64 rate; an upper
-            bound) and, when the instruction-class counters were captured, f64-class instructions at 4 and the
-            rest (32-bit integer / bit-field / convert / moves) at 2 (MI355X_MICROARCH.md: a wave issues a 32-bit
-            VALU instruction over 2 cycles)."""
+            """utilisation of the VALU issue slots: every wave instruction priced at 4 cycles.  That IS the rate of this
+            chip for everything these kernels issue (tools/ubench/valu_rate.hip, profiles/r03_valu_rate.txt: v_min/max
+            u32 4.1, v_min/fma/add f64 4.3, v_cndmask / v_lshl_or / v_mad_u32_u24 / v_mul_lo_u32 / DPP moves 4.2-4.3
+            cycles per wave instruction and SIMD; only v_add_f32 / v_add_u32 issue faster, 2.4-2.6).  The second figure
+            (f64-class at 4, the rest at 2) is kept for comparison with round 2's lines; it is a lower bound, not an estimate."""
             if not insts_per_group or seconds <= 0:
                 return None
             total = insts_per_group * groups
