@@ -182,7 +182,7 @@ class DeviceDataset {
     // root_off[t+1]) (original instance ids, in the order the sample is iterated), its sampled features
     // feats[t*nf .. t*nf+nf); every instance starts in node key t.
     struct RfActive { uint32_t tree, key, n; };
-    struct RfCand { double position, importance; uint32_t ids_i, flags, pos_l, pos_r; };
+    struct RfCand { double position, importance; uint32_t ids_i, flags, pos_l, pos_r; double sum_l, sum_r; };
     struct RfSplit { int32_t fslot; uint32_t pos, left, right; };
     // File-loaded datasets: bit f of bits_by_instance[id * words + f / 32] = instance id HOLDS feature f (the reference's
     // FeatureStats skips absent values, src/normalizers.rs:24-29, while the sort reads them as 0.0).  nullptr: all held.

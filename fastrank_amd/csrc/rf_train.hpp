@@ -302,7 +302,12 @@ class RFTrainer {
             stats_.candidates += cands.size();
             std::vector<frdev::DeviceDataset::RfSplit> splits(open.size());
             std::vector<Open> next;
-            struct Pending { size_t a; uint32_t left_n, right_n; };
+            struct Pending { size_t a; uint32_t left_n, right_n; double sum_l, sum_r; };
+            // SquaredError evaluates a candidate by summing the gains of both sides in the segment's order -- the same sums
+            // compute_output of the children divides (random_forest.rs:32-41, 395-398): taken from the chosen candidate, no
+            // second pass over the node (FR_RF_CHILDSUM=1: the separate pass, for comparison)
+            static const bool force_childsum = getenv("FR_RF_CHILDSUM") != nullptr;
+            const bool sums_from_cands = p_.split_method == 0 && !force_childsum;
             std::vector<Pending> pend;
             const uint32_t km1 = k >= 2 ? k - 1 : 0;
             for (size_t a = 0; a < open.size(); a++) {
@@ -311,11 +316,11 @@ class RFTrainer {
                 // label_stats: all labels equal -> no feature yields a candidate (random_forest.rs:218-221)
                 if (km1 == 0 || lab[a * 2] == lab[a * 2 + 1]) continue;
                 bool have = false;
-                double best_imp = 0.0, best_split = 0.0;
+                double best_imp = 0.0, best_split = 0.0, best_sl = 0.0, best_sr = 0.0;
                 uint32_t best_pos = 0, best_fi = 0;
                 for (uint32_t fi = 0; fi < nf; fi++) {
                     bool fhave = false;
-                    double fimp = 0.0, fsplit = 0.0;
+                    double fimp = 0.0, fsplit = 0.0, fsl = 0.0, fsr = 0.0;
                     uint32_t fpos = 0;
                     for (uint32_t c = 0; c < km1; c++) {
                         const auto& cd = cands[((size_t)a * nf + fi) * km1 + c];
@@ -336,6 +341,7 @@ class RFTrainer {
                             fimp = imp;
                             fsplit = cd.position;
                             fpos = cd.ids_i;
+                            fsl = cd.sum_l, fsr = cd.sum_r;
                         }
                     }
                     if (fhave && (!have || fimp >= best_imp)) {  // random_forest.rs:391-392
@@ -344,6 +350,7 @@ class RFTrainer {
                         best_split = fsplit;
                         best_pos = fpos;
                         best_fi = fi;
+                        best_sl = fsl, best_sr = fsr;
                     }
                 }
                 if (!have) continue;  // NoFeatureSplitCandidates: stays the leaf it is
@@ -355,13 +362,13 @@ class RFTrainer {
                 nd->rhs.reset(new TreeNode());
                 splits[a] = {(int32_t)best_fi, best_pos, next_key, next_key + 1};
                 next_key += 2;
-                pend.push_back({a, best_pos, o.n - best_pos});
+                pend.push_back({a, best_pos, o.n - best_pos, best_sl, best_sr});
                 stats_.nodes += 2;
             }
             std::vector<double> child_out;
             auto tp0 = tnow();
             stats_.t_select += secs(tl1, tp0);
-            if (!dev.rf_split(splits, &child_out, &err)) fail_str(err);
+            if (!dev.rf_split(splits, sums_from_cands ? nullptr : &child_out, &err)) fail_str(err);
             stats_.t_split += secs(tp0, tnow());
             for (const Pending& pd : pend) {
                 const Open& o = open[pd.a];
@@ -369,7 +376,8 @@ class RFTrainer {
                 const uint32_t ns[2] = {pd.left_n, pd.right_n};
                 for (int side = 0; side < 2; side++) {
                     kids[side]->leaf = true;
-                    kids[side]->value = child_out[pd.a * 2 + side];  // random_forest.rs:395-398
+                    // random_forest.rs:395-398 (gain_sum / len, 0.0 for an empty side: rf_childsum_kernel's formula)
+                    kids[side]->value = sums_from_cands ? (ns[side] ? (side ? pd.sum_r : pd.sum_l) / (double)ns[side] : 0.0) : child_out[pd.a * 2 + side];
                     const uint32_t key = side ? splits[pd.a].right : splits[pd.a].left;
                     if (enterable(ns[side], o.depth + 1)) next.push_back({o.tree, key, ns[side], kids[side], kids[side]->value, o.depth + 1});
                 }
