@@ -188,7 +188,10 @@ class DeviceDataset {
     // FeatureStats skips absent values, src/normalizers.rs:24-29, while the sort reads them as 0.0).  nullptr: all held.
     bool rf_set_presence(const uint32_t* bits_by_instance, size_t words, size_t n_instances, std::string* err);
     bool rf_begin(const std::vector<uint32_t>& root_off, const std::vector<uint32_t>& root_ids, uint32_t nf,
-                  const std::vector<uint32_t>& feats, std::string* err);
+                  const std::vector<uint32_t>& feats, std::string* err, const std::vector<uint32_t>* positions = nullptr);
+    // host only, callable from another thread while the device works: positions[g] = where instance root_ids[g] sits in the
+    // tiled layout (what rf_begin otherwise works out itself); hand the result to rf_begin
+    bool rf_positions(const std::vector<uint32_t>& root_ids, std::vector<uint32_t>* positions, std::string* err);
     // compute_output of every tree's whole sample (random_forest.rs:344-351: a root that does not split)
     bool rf_root_outputs(std::vector<double>* out, std::string* err);
     // one level: for every active node (slot = its index in `active`; slot_of_key maps node keys to slots, IDX for

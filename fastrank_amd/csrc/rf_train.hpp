@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <exception>
+#include <future>
 #include <thread>
 
 #include "host.hpp"
@@ -211,12 +212,21 @@ class RFTrainer {
             frdev::DeviceDataset& d;
             ~EndGuard() { d.rf_end(); }
         } end_guard{dev};
-        uint32_t t0 = part.t_begin;
-        while (t0 < part.t_end) {
+        // A batch's host side -- the trees' samples (sampling.rs:38-60) and where their instances sit on the device -- is made
+        // by another thread while the device grows the batch before it: 0.12 s per batch of eleven trees at the 30K shape,
+        // a quarter of the wall time when it ran in line.
+        struct Batch {
+            uint32_t t0 = 0, t1 = 0;
+            std::vector<uint32_t> root_off, root_ids, feats, positions;
+            double seconds = 0.0;
+        };
+        auto prepare = [this, &dev, &csr, budget, t_end = part.t_end](uint32_t t0) {
+            Batch b;
             const auto ts0 = std::chrono::steady_clock::now();
-            std::vector<uint32_t> root_off(1, 0), root_ids, feats;
+            b.t0 = t0;
+            b.root_off.assign(1, 0);
             uint32_t t1 = t0;
-            while (t1 < part.t_end) {
+            while (t1 < t_end) {
                 Rand64 local(seeds_[t1]);
                 std::vector<uint32_t> f = features_, q = queries_;
                 shuffle(f, local);  // randutil.rs:14-18: shuffle all, take the first n
@@ -225,26 +235,38 @@ class RFTrainer {
                 q.resize(n_queries_);
                 std::vector<char> chosen(csr.nq, 0);
                 for (uint32_t qi : q) chosen[qi] = 1;
-                const size_t before = root_ids.size();
+                const size_t before = b.root_ids.size();
                 for (size_t qi = 0; qi < csr.nq; qi++) {  // sampling.rs:56-60 in the dataset's query order
                     if (!chosen[qi]) continue;
                     const std::vector<uint32_t>& ids = qids_sorted_[qi];
-                    root_ids.insert(root_ids.end(), ids.begin(), ids.end());
+                    b.root_ids.insert(b.root_ids.end(), ids.begin(), ids.end());
                 }
-                const size_t items = root_ids.size() * n_features_;
+                const size_t items = b.root_ids.size() * n_features_;
                 if (t1 > t0 && (items * dev.rf_bytes_per_item() > budget || items >= (size_t(1) << 31))) {
-                    root_ids.resize(before);  // this tree opens the next batch
+                    b.root_ids.resize(before);  // this tree opens the next batch
                     break;
                 }
                 if (items >= (size_t(1) << 31)) fail_str("random forest: one tree's sample exceeds the device sort's index range");
-                feats.insert(feats.end(), f.begin(), f.end());
-                root_off.push_back((uint32_t)root_ids.size());
+                b.feats.insert(b.feats.end(), f.begin(), f.end());
+                b.root_off.push_back((uint32_t)b.root_ids.size());
                 t1++;
             }
-            stats.t_sample += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
-            grow_batch(dev, t0, t1, root_off, root_ids, (uint32_t)n_features_, feats, out, stats);
+            b.t1 = t1;
+            std::string perr;
+            if (!dev.rf_positions(b.root_ids, &b.positions, &perr)) fail_str(perr);
+            b.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+            return b;
+        };
+        if (part.t_begin >= part.t_end) return;
+        std::future<Batch> next = std::async(std::launch::async, prepare, part.t_begin);
+        for (;;) {
+            Batch b = next.get();
+            const bool more = b.t1 < part.t_end;
+            if (more) next = std::async(std::launch::async, prepare, b.t1);
+            stats.t_sample += b.seconds;
+            grow_batch(dev, b.t0, b.t1, b.root_off, b.root_ids, (uint32_t)n_features_, b.feats, &b.positions, out, stats);
             stats.batches++;
-            t0 = t1;
+            if (!more) break;
         }
     }
 
@@ -263,13 +285,14 @@ class RFTrainer {
     static uint32_t tree_depth(const TreeNode& n) { return n.leaf ? 1 : 1 + std::max(tree_depth(*n.lhs), tree_depth(*n.rhs)); }
 
     void grow_batch(frdev::DeviceDataset& dev, uint32_t t0, uint32_t t1, const std::vector<uint32_t>& root_off,
-                    const std::vector<uint32_t>& root_ids, uint32_t nf, const std::vector<uint32_t>& feats, Model& out, RFStats& stats_) {
+                    const std::vector<uint32_t>& root_ids, uint32_t nf, const std::vector<uint32_t>& feats,
+                    const std::vector<uint32_t>* positions, Model& out, RFStats& stats_) {
         const uint32_t T = t1 - t0;
         std::string err;
         auto tnow = [] { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         auto tb0 = tnow();
-        if (!dev.rf_begin(root_off, root_ids, nf, feats, &err)) fail_str(err);
+        if (!dev.rf_begin(root_off, root_ids, nf, feats, &err, positions)) fail_str(err);
         stats_.t_begin += secs(tb0, tnow());
         std::vector<std::shared_ptr<TreeNode>> roots(T);
         std::vector<Open> open;

@@ -123,6 +123,23 @@ def test_defaults_on_mslr_shape_with_ties_and_several_batches(batch_bytes, monke
     assert max(depths) > 10, "real trees expected"
 
 
+@pytest.mark.parametrize("method", ["SquaredError", "TrueVarianceReduction", "BinaryGiniImpurity", "InformationGain"])
+def test_fractional_and_huge_labels_keep_the_sequential_sums(method):
+    """Integer labels of moderate size let the device form a split's gain sums in integer arithmetic (any order is the
+    reference's f64 sum then, kernels_rf.inc RFArgs::labels_int); fractional labels -- and integers too large for that
+    argument -- must take the sequential chain, whose association is the reference's (random_forest.rs:32-51)."""
+    X, y, qid = synth_dataset(77, 5000, 16, 50, max_len=300)
+    rng = np.random.default_rng(5)
+    # (labels beyond 2^21 with a measure that only asks whether they are positive: 2^label overflows NDCG's gains)
+    for labels, measure in ((y + np.round(rng.random(len(y)), 3), "ndcg@10"), (y * 3.0e6, "map")):
+        g, c = fr.CDataset.from_numpy(X, labels, qid), o.Dataset(X, labels, qid)
+        req = _request(measure, seed=3, num_trees=6)
+        req.params.split_method = {method: []}
+        req.params.min_leaf_support = 5
+        exp, _ = _oracle(c, req)
+        assert g.train_model(req).to_dict() == exp
+
+
 def test_sampled_view_trains_on_its_own_queries_and_features(trec):
     """A query / feature subsample (the Python API's train-test split) trains on exactly its instances and features."""
     X, y, qid, g, c = trec
