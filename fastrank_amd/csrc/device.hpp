@@ -203,7 +203,9 @@ class DeviceDataset {
     // = compute_output of that child (random_forest.rs:32-41)
     bool rf_split(const std::vector<RfSplit>& splits, std::vector<double>* child_out, std::string* err);
     void rf_end();
-    size_t rf_bytes_per_item() const { return 32; }  // device bytes per (sampled instance x sampled feature) of a batch
+    // device bytes per (sampled instance x sampled feature) of a batch: two key and two payload arrays (8 + 8 + 4 + 4), the sorted
+    // gains and values (4 + 4), the side byte of the stable partition
+    size_t rf_bytes_per_item() const { return 33; }
 
     int take_flags();  // returns and clears the accumulated kernel error bits
 
