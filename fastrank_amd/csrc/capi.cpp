@@ -370,7 +370,7 @@ static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& vi
         std::string err;
         if (!frdev::set_device(devs[0], &err)) fr::fail_str(err);
     }
-    // The copies are made one after the other (they all read the first device's HBM), the training runs concurrently.
+    // The copies are made at the same time (one host thread per entry), then the training runs concurrently.
     // A device the dataset cannot be copied to is an error when FR_DEVICES named it; of the default "every visible
     // device" it is simply left out (the request then trains on the devices that took a copy).
     const bool explicit_list = std::getenv("FR_DEVICES") != nullptr;
@@ -379,13 +379,26 @@ static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& vi
         DevicePlan pl = plan_devices(devs, units, primary_dev);
         std::vector<int> kept;
         std::exception_ptr first_error;
+        // every entry's copy at the same time (each on its own device and stream, reading the first device over its own
+        // link); the slots are disjoint
+        std::vector<std::exception_ptr> errs(pl.devs.size());
+        {
+            std::vector<std::thread> copiers;
+            auto copy_to = [&](size_t i) {
+                try {
+                    (void)view->device_ptr(pl.slot[i], pl.devs[i]);
+                } catch (...) {
+                    errs[i] = std::current_exception();
+                }
+            };
+            (void)view->device_ptr();  // (the first copy exists before anything reads it)
+            for (size_t i = 1; i < pl.devs.size(); i++) copiers.emplace_back(copy_to, i);
+            copy_to(0);
+            for (auto& th : copiers) th.join();
+        }
         for (size_t i = 0; i < pl.devs.size(); i++) {
-            try {
-                (void)view->device_ptr(pl.slot[i], pl.devs[i]);
-                kept.push_back(pl.devs[i]);
-            } catch (...) {
-                if (!first_error) first_error = std::current_exception();
-            }
+            if (!errs[i]) kept.push_back(pl.devs[i]);
+            else if (!first_error) first_error = errs[i];
         }
         if (!first_error) return pl;
         if (explicit_list || kept.empty()) std::rethrow_exception(first_error);

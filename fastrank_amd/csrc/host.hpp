@@ -494,11 +494,15 @@ struct DatasetView {
         std::shared_ptr<frdev::DeviceDataset> owner_rep;
         const bool aliases_owner = owner != this && (primary.get() == owner->device_ptr().get() || primary->shares_parent_matrix());
         if (aliases_owner) owner_rep = owner->device_ptr(slot, device);
-        std::lock_guard<std::mutex> lk(mu);
-        if (replicas.size() < (size_t)slot) replicas.resize((size_t)slot);
-        std::shared_ptr<frdev::DeviceDataset>& r = replicas[(size_t)slot - 1];
-        if (r && r->device_ordinal() == device) return r;
-        r.reset();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (replicas.size() < (size_t)slot) replicas.resize((size_t)slot);
+            const std::shared_ptr<frdev::DeviceDataset>& have = replicas[(size_t)slot - 1];
+            if (have && have->device_ordinal() == device) return have;
+        }
+        // (the copy itself runs outside the lock: train_model makes the copies for all devices of its list at the same
+        // time -- every peer has its own xGMI link to the first device -- and no two callers ever fill the same slot)
+        std::shared_ptr<frdev::DeviceDataset> r;
         std::string err;
         if (aliases_owner) {
             if (!primary->shares_parent_matrix()) {
@@ -512,6 +516,9 @@ struct DatasetView {
             r = frdev::DeviceDataset::replicate(primary, device, &err);
         }
         if (!r) fail_str(err.empty() ? "could not copy the dataset to device " + std::to_string(device) : err);
+        std::lock_guard<std::mutex> lk(mu);
+        if (replicas.size() < (size_t)slot) replicas.resize((size_t)slot);
+        replicas[(size_t)slot - 1] = r;
         return r;
     }
     frdev::DeviceDataset& device() { return *device_ptr(); }
