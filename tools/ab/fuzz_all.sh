@@ -9,5 +9,7 @@ echo "# the same under FR_LS_PIPELINE=0 and FR_LS_FIFO=1"
 FR_LS_PIPELINE=0 python tools/fuzz_parity.py --iters 300 --seed 303 --long 2>&1 | tail -1
 FR_LS_FIFO=1 python tools/fuzz_parity.py --iters 300 --seed 304 --long 2>&1 | tail -1
 echo "# tools/fuzz_rf.py (random-forest training vs oracle)"
-python tools/fuzz_rf.py --iters 600 --seed 305 2>&1 | tail -2
+python tools/fuzz_rf.py --iters 1500 --seed 305 2>&1 | tail -2
+echo "# tools/fuzz_trees.py (forest scoring vs oracle)"
+python tools/fuzz_trees.py --iters 300 2>&1 | tail -1
 } | tee gpurun_out/fuzz/r03_fuzz.txt

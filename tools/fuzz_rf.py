@@ -28,7 +28,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
     t0 = time.time()
-    bad = errs = nodes = sampled = 0
+    bad = errs = nodes = sampled = fanned = 0
     methods = {}
     for it in range(args.iters):
         X, y, qid, measure, _ = make_case(rng)
@@ -36,6 +36,11 @@ def main():
             os.environ["FR_RF_BATCH_BYTES"] = str(int(rng.integers(20000, 400000)))
         else:
             os.environ.pop("FR_RF_BATCH_BYTES", None)
+        if rng.random() < 0.2:  # the trees spread over two or three contexts on this device (capi.cpp, train_rf)
+            os.environ["FR_DEVICES"] = str(rng.choice(["0,0", "0,0,0"]))
+            fanned += 1
+        else:
+            os.environ.pop("FR_DEVICES", None)
         g = fr.CDataset.from_numpy(X, y, qid)
         fids = np.arange(X.shape[1], dtype=np.uint32)
         if rng.random() < 0.3 and len(np.unique(qid)) > 2:
@@ -84,7 +89,7 @@ def main():
             bad += 1
             print("MISMATCH iter", it, json.dumps({"n": len(y), "d": X.shape[1], "measure": measure, "params": p.to_dict()}))
     print(json.dumps({"iters": args.iters, "mismatches": bad, "both_error": errs, "split_nodes": nodes, "methods": methods,
-                      "sampled_views": sampled, "seconds": round(time.time() - t0, 1)}))
+                      "sampled_views": sampled, "over_several_contexts": fanned, "seconds": round(time.time() - t0, 1)}))
     return 1 if bad else 0
 
 
