@@ -329,7 +329,7 @@ class RFTrainer {
             // SquaredError evaluates a candidate by summing the gains of both sides in the segment's order -- the same sums
             // compute_output of the children divides (random_forest.rs:32-41, 395-398): taken from the chosen candidate, no
             // second pass over the node (FR_RF_CHILDSUM=1: the separate pass, for comparison)
-            static const bool force_childsum = getenv("FR_RF_CHILDSUM") != nullptr;
+            const bool force_childsum = getenv("FR_RF_CHILDSUM") != nullptr;
             const bool sums_from_cands = p_.split_method == 0 && !force_childsum;
             std::vector<Pending> pend;
             const uint32_t km1 = k >= 2 ? k - 1 : 0;

@@ -140,6 +140,23 @@ def test_fractional_and_huge_labels_keep_the_sequential_sums(method):
         assert g.train_model(req).to_dict() == exp
 
 
+@pytest.mark.parametrize("env", [{"FR_RF_PARTITION": "0"}, {"FR_RF_INT_SUMS": "0"}, {"FR_RF_CHILDSUM": "1"},
+                                 {"FR_RF_PARTITION": "0", "FR_RF_INT_SUMS": "0", "FR_RF_CHILDSUM": "1", "FR_RF_RESORT": "1"}])
+def test_round2_formulations_grow_the_same_forest(env, monkeypatch):
+    """Round 3 replaced three pieces of the level step -- rekey + radix sort by a stable partition, the gain sums' chain by
+    integer arithmetic (integer labels), the children's sums by the chosen candidate's -- and keeps the round-2
+    formulation of each behind a switch: every combination must grow the forest the oracle grows."""
+    X, y, qid = synth_dataset(303, 7000, 20, 70, max_len=300)
+    X[:, ::4] = np.floor(X[:, ::4] * 2)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = _request("ndcg@10", seed=11, num_trees=8, min_leaf_support=4)
+    exp, _ = _oracle(c, req)
+    assert g.train_model(req).to_dict() == exp
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert g.train_model(req).to_dict() == exp
+
+
 def test_sampled_view_trains_on_its_own_queries_and_features(trec):
     """A query / feature subsample (the Python API's train-test split) trains on exactly its instances and features."""
     X, y, qid, g, c = trec
