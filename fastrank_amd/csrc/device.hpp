@@ -204,8 +204,8 @@ class DeviceDataset {
     bool rf_split(const std::vector<RfSplit>& splits, std::vector<double>* child_out, std::string* err);
     void rf_end();
     // device bytes per (sampled instance x sampled feature) of a batch: two key and two payload arrays (8 + 8 + 4 + 4), the sorted
-    // gains and values (4 + 4), the side byte of the stable partition
-    size_t rf_bytes_per_item() const { return 33; }
+    // gains and values of this level and the one before (4 x 4), the side byte of the stable partition
+    size_t rf_bytes_per_item() const { return 41; }
 
     int take_flags();  // returns and clears the accumulated kernel error bits
 

@@ -199,10 +199,10 @@ class RFTrainer {
             std::string perr;
             if (!dev.rf_set_presence(core.present_bits.empty() ? nullptr : core.present_bits.data(), core.present_words, core.n, &perr)) fail_str(perr);
         }
-        // batches sized by device memory: rf_bytes_per_item per (sampled instance x sampled feature), at most 24 GB and at
+        // batches sized by device memory: rf_bytes_per_item per (sampled instance x sampled feature), at most 30 GB and at
         // most 40 % of what is free right now (the sort's scratch, the candidate tables and the per-tree score buffers
         // come on top)
-        size_t budget = (size_t)24 << 30;
+        size_t budget = (size_t)30 << 30;
         {
             const size_t free_b = frdev::device_free_bytes();
             if (free_b != 0) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, free_b / 5 * 2));
