@@ -188,10 +188,10 @@ class DeviceDataset {
     // FeatureStats skips absent values, src/normalizers.rs:24-29, while the sort reads them as 0.0).  nullptr: all held.
     bool rf_set_presence(const uint32_t* bits_by_instance, size_t words, size_t n_instances, std::string* err);
     bool rf_begin(const std::vector<uint32_t>& root_off, const std::vector<uint32_t>& root_ids, uint32_t nf,
-                  const std::vector<uint32_t>& feats, std::string* err, const std::vector<uint32_t>* positions = nullptr);
+                  const std::vector<uint32_t>& feats, std::string* err, const uint32_t* positions = nullptr);
     // host only, callable from another thread while the device works: positions[g] = where instance root_ids[g] sits in the
     // tiled layout (what rf_begin otherwise works out itself); hand the result to rf_begin
-    bool rf_positions(const std::vector<uint32_t>& root_ids, std::vector<uint32_t>* positions, std::string* err);
+    bool rf_positions(const std::vector<uint32_t>& root_ids, uint32_t* positions /*[root_ids.size()]*/, std::string* err);
     // compute_output of every tree's whole sample (random_forest.rs:344-351: a root that does not split)
     bool rf_root_outputs(std::vector<double>* out, std::string* err);
     // one level: for every active node (slot = its index in `active`; slot_of_key maps node keys to slots, IDX for
@@ -226,6 +226,10 @@ void profile_reset();
 std::vector<KernelStat> profile_stats();
 bool device_synchronize(std::string* err);
 size_t device_free_bytes();
+// page-locked host memory (nullptr when none is left: the caller falls back to ordinary memory); for staging uploads that
+// a helper thread prepares -- a copy from ordinary memory ran at under 1 GB/s on some of the boxes this was measured on
+void* pinned_alloc(size_t bytes);
+void pinned_free(void* p);
 // size class of the full-ranking kernel a query of `len` documents is sorted in: *nl keys per lane, *pl lanes per candidate
 // (no device needed; fullverify.hpp FV_CLASSES)
 void fullrank_class_of(uint32_t len, uint32_t* nl, uint32_t* pl);  // free HBM on the current device (0 if unknown)

@@ -217,10 +217,28 @@ class RFTrainer {
         // a quarter of the wall time when it ran in line.
         struct Batch {
             uint32_t t0 = 0, t1 = 0;
-            std::vector<uint32_t> root_off, root_ids, feats, positions;
+            std::vector<uint32_t> root_off, root_ids, feats;
+            uint32_t* positions = nullptr;  // in one of the two page-locked slabs below (or in positions_own)
+            std::vector<uint32_t> positions_own;
             double seconds = 0.0;
         };
-        auto prepare = [this, &dev, &csr, budget, t_end = part.t_end](uint32_t t0) {
+        // two page-locked slabs for the batches' instance positions (the one big upload of a batch), used in turn: one is on
+        // the wire while the helper thread fills the other
+        struct Slab {
+            uint32_t* p = nullptr;
+            size_t cap = 0;
+            ~Slab() { frdev::pinned_free(p); }
+            uint32_t* get(size_t count) {
+                if (count > cap) {
+                    frdev::pinned_free(p);
+                    p = static_cast<uint32_t*>(frdev::pinned_alloc(std::max<size_t>(count, 1) * sizeof(uint32_t)));
+                    cap = p ? count : 0;
+                }
+                return p;
+            }
+        } slabs[2];
+        uint32_t batch_no = 0;
+        auto prepare = [this, &dev, &csr, &slabs, budget, t_end = part.t_end](uint32_t t0, uint32_t which) {
             Batch b;
             const auto ts0 = std::chrono::steady_clock::now();
             b.t0 = t0;
@@ -253,18 +271,23 @@ class RFTrainer {
             }
             b.t1 = t1;
             std::string perr;
-            if (!dev.rf_positions(b.root_ids, &b.positions, &perr)) fail_str(perr);
+            b.positions = slabs[which & 1u].get(b.root_ids.size());
+            if (b.positions == nullptr) {
+                b.positions_own.resize(b.root_ids.size());
+                b.positions = b.positions_own.data();
+            }
+            if (!dev.rf_positions(b.root_ids, b.positions, &perr)) fail_str(perr);
             b.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
             return b;
         };
         if (part.t_begin >= part.t_end) return;
-        std::future<Batch> next = std::async(std::launch::async, prepare, part.t_begin);
+        std::future<Batch> next = std::async(std::launch::async, prepare, part.t_begin, batch_no++);
         for (;;) {
             Batch b = next.get();
             const bool more = b.t1 < part.t_end;
-            if (more) next = std::async(std::launch::async, prepare, b.t1);
+            if (more) next = std::async(std::launch::async, prepare, b.t1, batch_no++);
             stats.t_sample += b.seconds;
-            grow_batch(dev, b.t0, b.t1, b.root_off, b.root_ids, (uint32_t)n_features_, b.feats, &b.positions, out, stats);
+            grow_batch(dev, b.t0, b.t1, b.root_off, b.root_ids, (uint32_t)n_features_, b.feats, b.positions, out, stats);
             stats.batches++;
             if (!more) break;
         }
@@ -286,7 +309,7 @@ class RFTrainer {
 
     void grow_batch(frdev::DeviceDataset& dev, uint32_t t0, uint32_t t1, const std::vector<uint32_t>& root_off,
                     const std::vector<uint32_t>& root_ids, uint32_t nf, const std::vector<uint32_t>& feats,
-                    const std::vector<uint32_t>* positions, Model& out, RFStats& stats_) {
+                    const uint32_t* positions, Model& out, RFStats& stats_) {
         const uint32_t T = t1 - t0;
         std::string err;
         auto tnow = [] { return std::chrono::steady_clock::now(); };
