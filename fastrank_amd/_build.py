@@ -9,6 +9,7 @@ The objects are compiled in parallel (fullverify.hip once per slice of the size 
 a few objects.
 """
 import concurrent.futures
+import fcntl
 import os
 import re
 import shutil
@@ -85,13 +86,14 @@ def needs_build() -> bool:
 
 def _compile(hipcc, obj, src, extra, verbose):
     path = os.path.join(OBJ_DIR, obj)
-    cmd = [hipcc] + FLAGS + _extra_flags() + extra + ["-c", os.path.join(CSRC, src), "-o", path + ".tmp"]
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    cmd = [hipcc] + FLAGS + _extra_flags() + extra + ["-c", os.path.join(CSRC, src), "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed on %s %s:\n%s" % (src, " ".join(extra), proc.stdout))
-    os.replace(path + ".tmp", path)
+    os.replace(tmp, path)
     with open(path + ".flags", "w") as fh:
         fh.write(" ".join(_extra_flags()))
     return obj
@@ -101,6 +103,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time per tree: processes that import the package together on a fresh tree (the ranks of a
+    # torch.distributed.run launch) queue up here, and all but the first find the library current when their turn comes
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = hipcc_path()
     todo = [(o, s, e) for o, s, e, d in units() if force or _stale(o, s, d)]
     jobs = max(1, min(len(todo), int(os.environ.get("FR_BUILD_JOBS", str(os.cpu_count() or 4)))))
@@ -110,13 +125,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             for f in futs:
                 f.result()
     objs = [os.path.join(OBJ_DIR, o) for o, _, _, _ in units()]
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp", "-lz"]
+    tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("link failed:\n" + proc.stdout)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(tmp, LIB_PATH)
     with open(LIB_PATH + ".flags", "w") as fh:
         fh.write(" ".join(_extra_flags()))
     return LIB_PATH

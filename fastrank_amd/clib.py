@@ -92,6 +92,8 @@ def _load():
         "fr_synchronize": (C.c_int, []),
         "fr_debug_device_plan": (vp, [C.c_char_p, C.c_int, C.c_uint32, C.c_int]),
         "fr_debug_fullrank_class": (C.c_uint32, [C.c_uint32]),
+        "fr_debug_restart_queue": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]),
+        "fr_dataset_release_replicas": (sz, [vp]),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(L, name)
@@ -225,15 +227,15 @@ class CModel:
         return CModel(_unwrap(_load().model_from_json(json.dumps(model_json).encode("utf-8"))))
 
     def predict_dense_scores(self, dataset: "CDataset", missing: float = float("nan")) -> List[float]:
-        output: List[float] = []
-        for index, score in sorted(self.predict_scores(dataset).items()):
-            while len(output) < index:
-                output.append(missing)
-            if index == len(output):
-                output.append(score)
-            else:
-                output[index] = score
-        return output
+        """Scores as a list indexed by instance id, 0 .. the largest id the dataset view holds; ids it does not hold
+        (a sampled view) read `missing` (same result as fastrank/clib.py:159-168)."""
+        by_id = self.predict_scores(dataset)
+        if not by_id:
+            return []
+        dense = [missing] * (max(by_id) + 1)
+        for index, score in by_id.items():
+            dense[index] = score
+        return dense
 
     def predict_scores(self, dataset: "CDataset") -> Dict[int, float]:
         self._require_init()

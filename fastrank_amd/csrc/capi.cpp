@@ -1,5 +1,6 @@
 // extern "C" boundary of libfastrank_amd.so -- see include/fastrank.h for the contract and the
 // reference file:line each symbol replaces (src/lib.rs, src/ffi.rs, src/json_api.rs).
+#include <atomic>
 #include <limits>
 #include <chrono>
 #include <cstdio>
@@ -154,6 +155,8 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("audit_values", Value::uint(s.audit_values));
     o.set("audit_mismatches", Value::uint(s.audit_mismatches));
     o.set("devices", Value::uint(s.devices));
+    o.set("refills", Value::uint(s.refills));
+    if (s.device >= 0) o.set("device", Value::uint((uint64_t)s.device));
     return o;
 }
 
@@ -245,20 +248,33 @@ std::string rust_display_f64(double v) {
     return out;
 }
 
-static void set_last_stats(const fr::TrainStats& st) {
+std::vector<fr::TrainStats> g_last_per_device;  // one entry per device of the last multi-device train_model call
+static void set_last_stats(const fr::TrainStats& st, std::vector<fr::TrainStats> per_device = {}) {
     std::lock_guard<std::mutex> lk(g_stats_mu);
     g_last_stats = st;
+    g_last_per_device = std::move(per_device);
 }
 
-// restarts [rbegin, rend) of a request on one device-side copy of the view (slot, device: DatasetView::device_ptr)
-static std::vector<fr::RestartResult> train_ca_range(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq,
-                                                     const fr::Evaluator& ev, uint32_t rbegin, uint32_t rend, int slot, int device,
-                                                     fr::TrainStats* stats_out) {
+// Per-trainer bound on the restarts kept live at once (FR_RESTART_SLOTS, default 64): a request with more restarts than
+// that per device runs them through the restart queue, converged restarts handing their places to the next ids -- the
+// resident sums, result matrices and launch width stay those of 64 restarts however many the request names.
+static uint32_t restart_slots_max() {
+    const char* e = std::getenv("FR_RESTART_SLOTS");
+    const long v = e ? std::atol(e) : 64;
+    return (uint32_t)std::min<long>(std::max<long>(v, 1), 1 << 20);
+}
+
+// the restarts `queue` still holds (at most `capacity` live at a time) on one device-side copy of the view (slot, device:
+// DatasetView::device_ptr)
+static std::vector<fr::RestartResult> train_ca_queue(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq,
+                                                     const fr::Evaluator& ev, std::shared_ptr<fr::RestartQueue> queue, uint32_t capacity,
+                                                     int slot, int device, fr::TrainStats* stats_out) {
     auto t0 = std::chrono::steady_clock::now();
-    fr::CATrainer trainer(view, ev, rq.ca, rbegin, rend, fr::QueryShard(), slot, device);
+    fr::CATrainer trainer(view, ev, rq.ca, std::move(queue), capacity, fr::QueryShard(), slot, device);
     while (trainer.run(64, nullptr)) {
     }
     trainer.stats().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    trainer.stats().device = device;
     if (stats_out) *stats_out = trainer.stats();
     return trainer.results();
 }
@@ -268,7 +284,9 @@ fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
     if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
     fr::TrainStats st;
-    std::vector<fr::RestartResult> hist = train_ca_range(view, rq, ev, rbegin, rend, 0, -1, &st);
+    rend = std::min(rend, rq.ca.num_restarts);
+    std::vector<fr::RestartResult> hist =
+        train_ca_queue(view, rq, ev, std::make_shared<fr::RestartQueue>(rbegin, rend), restart_slots_max(), 0, -1, &st);
     set_last_stats(st);
     fr::Model m;
     if (hist_out) {
@@ -288,7 +306,7 @@ fr::Model train_ca(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
 // one (DeviceDataset::replicate, hipMemcpyPeer over xGMI) -- and the results are gathered in host memory and selected
 // like a single trainer's history (last maximum, or the score-weighted ensemble: :232-251).  No collective: this is
 // the in-process form of native.train_model_distributed.
-static int g_pinned_device = -1;  // fr_set_device: an explicit choice of ONE device for this process
+static std::atomic<int> g_pinned_device{-1};  // fr_set_device: an explicit choice of ONE device for this process
 
 static std::vector<int> parse_device_list(const char* e, int count) {
     std::vector<int> devs;
@@ -310,7 +328,7 @@ static std::vector<int> parse_device_list(const char* e, int count) {
 std::vector<int> fr_train_devices() {
     const int count = frdev::device_count(nullptr);
     if (const char* e = std::getenv("FR_DEVICES")) return parse_device_list(e, count);
-    if (g_pinned_device >= 0) return {g_pinned_device};
+    if (const int pinned = g_pinned_device.load(); pinned >= 0) return {pinned};
     std::vector<int> devs;
     for (int d = 0; d < count; d++) devs.push_back(d);
     return devs;
@@ -347,22 +365,45 @@ static DevicePlan plan_devices(std::vector<int> devs, uint32_t R, int primary_de
     return pl;
 }
 
+// Fewest restarts a device must get before the DEFAULT device list (every visible device) adds it to a request
+// (FR_MIN_RESTARTS_PER_DEVICE, default 4; an explicit FR_DEVICES is taken as given).  Measured on one MI355X at the 30K
+// shape (tools/tick_sweep.py, profiles/r04_tick_vs_groups.json): a tick of G line groups takes 0.11 + 0.083 G ms
+// (0.21 / 0.28 / 0.34 / 0.43 / 0.74 / 2.75 ms at G = 1 / 2 / 3 / 4 / 8 / 32), i.e. a device with one restart delivers 40 %
+// of the evaluations per second it delivers with 32, with four 80 %; every further device also costs a device-to-device
+// copy of the dataset the first time (2.2 GB) and the runtime's start-up there.  With the floor at 4 the reference's
+// default request (5 restarts, coordinate_ascent.rs:29) stays on one GPU and 32 restarts spread over 8.
+static uint32_t min_restarts_per_device() {
+    const char* e = std::getenv("FR_MIN_RESTARTS_PER_DEVICE");
+    const long v = e ? std::atol(e) : 4;
+    return (uint32_t)std::min<long>(std::max<long>(v, 1), 1 << 20);
+}
+
 // The device list of one train_model call over `units` independent pieces of work (restarts, trees), with the view's
-// device-side copies made: an empty / one-entry plan means "train on the current device, slot 0".
-static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& view, uint32_t units) {
+// device-side copies made: an empty / one-entry plan means "train on one device" (slot 0 = the view's first device
+// form; slot 1 = a copy on the one device an explicit list names when the first form lives elsewhere).
+static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& view, uint32_t units, uint32_t min_units_per_device = 1) {
     std::vector<int> devs = fr_train_devices();
-    // a small matrix is not worth a context on every GPU (each costs a device-to-device copy and, the first time, the
-    // runtime's per-device start-up); an explicit FR_DEVICES is taken as given
-    if (!std::getenv("FR_DEVICES") && view->instances.size() * (size_t)view->core->d < (size_t(1) << 23)) devs.resize(std::min<size_t>(devs.size(), 1));
+    const bool explicit_list = std::getenv("FR_DEVICES") != nullptr;
+    if (!explicit_list) {
+        // a small matrix is not worth a context on every GPU (each costs a device-to-device copy and, the first time, the
+        // runtime's per-device start-up), and neither is a device that would get fewer than the floor of units
+        if (view->instances.size() * (size_t)view->core->d < (size_t(1) << 23)) devs.resize(std::min<size_t>(devs.size(), 1));
+        const size_t by_floor = std::max<size_t>(1, units / std::max<uint32_t>(min_units_per_device, 1));
+        devs.resize(std::min(devs.size(), by_floor));
+    }
     if (devs.size() > units) devs.resize(std::max<uint32_t>(units, 1));
     auto single = [&](const std::vector<int>& d, bool pin) {
-        if (!d.empty() && pin) {
+        if (d.empty()) return plan_devices(d, units, -1);
+        if (pin) {
             std::string err;
             if (!frdev::set_device(d[0], &err)) fr::fail_str(err);
         }
-        return plan_devices(std::vector<int>(d.begin(), d.begin() + std::min<size_t>(d.size(), 1)), units, d.empty() ? -1 : d[0]);
+        // an explicit choice of a device other than the one the first device form already lives on: train on a copy there
+        const int have = view->built_on_device();
+        const int primary = (pin && have >= 0 && have != d[0]) ? have : d[0];
+        return plan_devices(std::vector<int>(1, d[0]), units, primary);
     };
-    if (devs.size() <= 1) return single(devs, std::getenv("FR_DEVICES") || g_pinned_device >= 0);
+    if (devs.size() <= 1) return single(devs, explicit_list || g_pinned_device.load() >= 0);
     if (view->host_csr().nq == 0) return single(devs, false);  // (the trainer reports the empty dataset its own way)
     // slot 0 is the device form the view already has (or builds now, on the first listed device); every other entry of
     // the list gets the next slot
@@ -373,7 +414,6 @@ static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& vi
     // The copies are made at the same time (one host thread per entry), then the training runs concurrently.
     // A device the dataset cannot be copied to is an error when FR_DEVICES named it; of the default "every visible
     // device" it is simply left out (the request then trains on the devices that took a copy).
-    const bool explicit_list = std::getenv("FR_DEVICES") != nullptr;
     const int primary_dev = view->device_ptr()->device_ordinal();
     for (;;) {
         DevicePlan pl = plan_devices(devs, units, primary_dev);
@@ -410,22 +450,27 @@ static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& vi
 fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq) {
     const uint32_t R = rq.ca.num_restarts;
     auto t0 = std::chrono::steady_clock::now();
-    const DevicePlan pl = devices_for_request(view, R);
-    if (pl.devs.size() <= 1) return train_ca(view, rq, 0, R, nullptr);
+    const DevicePlan pl = devices_for_request(view, R, min_restarts_per_device());
+    if (pl.devs.empty() || (pl.devs.size() == 1 && pl.slot[0] == 0)) return train_ca(view, rq, 0, R, nullptr);
     fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
-    std::vector<int> devs;
+    if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
     const size_t k = pl.devs.size();
-    const std::vector<int>& slot = pl.slot;
-    devs = pl.devs;
+    // One queue of restart ids for all devices (the reference's rayon pool, src/coordinate_ascent.rs:215-225): every
+    // trainer starts with its share and, once restarts of its own have converged, takes the next ids nobody has started.
+    // FR_RESTART_QUEUE=0: the static block partition of round 3 (entry i trains block i of the ids) -- same model.
+    const char* qe = std::getenv("FR_RESTART_QUEUE");
+    const bool shared_queue = !(qe && qe[0] == '0');
+    const uint32_t capacity = std::min<uint32_t>(restart_slots_max(), (uint32_t)((R + k - 1) / k));
+    auto queue = std::make_shared<fr::RestartQueue>(0, R);
     std::vector<std::vector<fr::RestartResult>> parts(k);
     std::vector<fr::TrainStats> stats(k);
     std::vector<std::exception_ptr> errors(k);
     auto work = [&](size_t i) {
         try {
-            const uint32_t b = pl.begin[i], e = pl.end[i];
             std::string err;
-            if (!frdev::set_device(devs[i], &err)) fr::fail_str(err);
-            parts[i] = train_ca_range(view, rq, ev, b, e, slot[i], devs[i], &stats[i]);
+            if (!frdev::set_device(pl.devs[i], &err)) fr::fail_str(err);
+            auto q = shared_queue ? queue : std::make_shared<fr::RestartQueue>(pl.begin[i], pl.end[i]);
+            parts[i] = train_ca_queue(view, rq, ev, std::move(q), shared_queue ? capacity : restart_slots_max(), pl.slot[i], pl.devs[i], &stats[i]);
         } catch (...) {
             errors[i] = std::current_exception();
         }
@@ -443,15 +488,19 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
         if (i == 0) continue;
         total.useful_evals += stats[i].useful_evals, total.raw_evals += stats[i].raw_evals;
         total.ticks = std::max(total.ticks, stats[i].ticks), total.groups += stats[i].groups;
-        total.restarts += stats[i].restarts;
+        total.restarts += stats[i].restarts, total.refills += stats[i].refills;
         total.verify_pairs += stats[i].verify_pairs, total.verify_redone += stats[i].verify_redone;
         total.line_searches += stats[i].line_searches, total.exact_ticks += stats[i].exact_ticks;
         total.audit_values += stats[i].audit_values, total.audit_mismatches += stats[i].audit_mismatches;
     }
     std::sort(hist.begin(), hist.end(), [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });
+    if (hist.size() != R) fr::fail_str("internal error: the devices trained " + std::to_string(hist.size()) + " of " + std::to_string(R) + " restarts");
+    for (uint32_t r = 0; r < R; r++)
+        if (hist[r].restart_id != r) fr::fail_str("internal error: restart " + std::to_string(r) + " was not trained exactly once");
     total.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     total.devices = (uint32_t)k;
-    set_last_stats(total);
+    total.device = -1;
+    set_last_stats(total, stats);
     return fr::ca_select(hist, rq.ca.output_ensemble);
 }
 
@@ -463,7 +512,7 @@ fr::Model train_rf(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     // the trees of a forest are independent given their seeds (random_forest.rs:301-331 grows them with rayon): spread
     // over FR_DEVICES like a coordinate-ascent request's restarts, block i of the trees on entry i of the list
     std::vector<fr::RFTrainer::DevicePart> parts;
-    if (rq.rf.num_trees > 0) {
+    if (rq.rf.num_trees > 0 && rq.rf.quiet) {  // (a forest that prints its progress table grows on one device: no copies made)
         const DevicePlan pl = devices_for_request(view, rq.rf.num_trees);
         if (pl.devs.size() > 1)
             for (size_t i = 0; i < pl.devs.size(); i++) parts.push_back(fr::RFTrainer::DevicePart{pl.slot[i], pl.devs[i], pl.begin[i], pl.end[i]});
@@ -849,9 +898,6 @@ const void* predict_to_trecrun(const CModel* model, const CDataset* dataset, con
 
 int fr_device_count(void) { return frdev::device_count(nullptr); }
 
-// How train_model would spread `num_restarts` restarts over the devices of `devices_csv` (the FR_DEVICES syntax) on a
-// node with `device_count` devices whose first device form lives on `primary_device`: {"devices","slots","blocks"}.
-// No device is touched (the CPU tests check the partition and the list parsing with it).
 // keys per lane << 16 | lanes per candidate of the full-ranking kernel's size class for a query of `len` documents
 uint32_t fr_debug_fullrank_class(uint32_t len) {
     uint32_t nl = 0, pl = 0;
@@ -859,6 +905,60 @@ uint32_t fr_debug_fullrank_class(uint32_t len) {
     return (nl << 16) | pl;
 }
 
+// The restart queue without a device: n_workers "trainers" of `capacity` places each, restart r converges after
+// lengths[r % n_lengths] ticks, places are refilled at the end of a tick (include/fastrank.h).
+const void* fr_debug_restart_queue(uint32_t num_restarts, uint32_t n_workers, uint32_t capacity, const uint32_t* lengths,
+                                   uint32_t n_lengths) {
+    return json_call([&]() {
+        if (n_workers == 0 || capacity == 0 || !lengths || n_lengths == 0) fr::fail_str("fr_debug_restart_queue: bad arguments");
+        fr::RestartQueue queue(0, num_restarts);
+        struct Place { uint32_t id, left; };
+        std::vector<std::vector<Place>> live(n_workers);
+        std::vector<std::vector<uint32_t>> order(n_workers);
+        std::vector<uint64_t> ticks(n_workers, 0);
+        auto fill = [&](uint32_t w) {
+            uint32_t id = 0;
+            while (live[w].size() < capacity && queue.pop(&id)) {
+                live[w].push_back(Place{id, std::max<uint32_t>(lengths[id % n_lengths], 1)});
+                order[w].push_back(id);
+            }
+        };
+        for (uint32_t w = 0; w < n_workers; w++) fill(w);
+        for (bool any = true; any;) {
+            any = false;
+            for (uint32_t w = 0; w < n_workers; w++) {
+                if (live[w].empty()) continue;
+                any = true;
+                ticks[w]++;
+                for (auto& p : live[w]) p.left--;
+                live[w].erase(std::remove_if(live[w].begin(), live[w].end(), [](const Place& p) { return p.left == 0; }), live[w].end());
+                fill(w);
+            }
+        }
+        Value o = Value::object(), ord = Value::array(), tk = Value::array();
+        for (uint32_t w = 0; w < n_workers; w++) {
+            Value a = Value::array();
+            for (uint32_t id : order[w]) a.push(Value::uint(id));
+            ord.push(std::move(a));
+            tk.push(Value::uint(ticks[w]));
+        }
+        o.set("order", std::move(ord));
+        o.set("ticks", std::move(tk));
+        return frjson::dump(o);
+    });
+}
+
+size_t fr_dataset_release_replicas(const CDataset* dataset) {
+    if (!dataset || !dataset->view) return 0;
+    std::lock_guard<std::mutex> lk(api_mu_of(*dataset));
+    size_t n = 0;
+    for (fr::DatasetView* v = dataset->view.get(); v; v = v->parent.get()) n += v->release_replicas();
+    return n;
+}
+
+// The device plan of a request of `num_restarts` units over the devices of `devices_csv` (the FR_DEVICES syntax) on a
+// node with `device_count` devices whose first device form lives on `primary_device`: {"devices","slots","blocks"}.
+// No device is touched (the CPU tests check the partition and the list parsing with it).
 const void* fr_debug_device_plan(const void* devices_csv, int device_count, uint32_t num_restarts, int primary_device) {
     return json_call([&]() {
         const std::string csv = accept_str("devices_csv", devices_csv);
@@ -1024,7 +1124,13 @@ const CResult* fr_select_model(const void* restarts_json, int output_ensemble) {
 const void* fr_last_train_stats(void) {
     return json_call([&]() {
         std::lock_guard<std::mutex> slk(g_stats_mu);
-        return frjson::dump(stats_to_json(g_last_stats));
+        Value o = stats_to_json(g_last_stats);
+        if (!g_last_per_device.empty()) {  // what every device of the call did (ticks above = the longest device's)
+            Value a = Value::array();
+            for (const fr::TrainStats& st : g_last_per_device) a.push(stats_to_json(st));
+            o.set("per_device", std::move(a));
+        }
+        return frjson::dump(o);
     });
 }
 

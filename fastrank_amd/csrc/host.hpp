@@ -4,6 +4,7 @@
 // (src/coordinate_ascent.rs:87-254) and feeds the device batches of candidates.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -521,6 +522,19 @@ struct DatasetView {
         replicas[(size_t)slot - 1] = r;
         return r;
     }
+    // drops the copies on other devices / in other contexts (slot 0 stays); returns how many there were
+    size_t release_replicas() {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t n = 0;
+        for (auto& r : replicas) n += r ? 1 : 0;
+        replicas.clear();
+        return n;
+    }
+    // ordinal of the device the first device form lives on; -1 while there is none yet
+    int built_on_device() {
+        std::lock_guard<std::mutex> lk(mu);
+        return dev ? dev->device_ordinal() : -1;
+    }
     frdev::DeviceDataset& device() { return *device_ptr(); }
     frdev::DeviceDataset& device(int slot, int dev_ordinal) { return *device_ptr(slot, dev_ordinal); }
     const frdev::HostCSR& host_csr() {
@@ -784,6 +798,8 @@ struct TrainStats {
     uint64_t audit_values = 0, audit_mismatches = 0;  // FR_VERIFY_AUDIT=1 (see include/fastrank.h)
     uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone after a tick with > 25 % redone pairs
     uint32_t devices = 1;      // devices train_model spread the restarts over (ticks = the longest device's)
+    uint32_t refills = 0;      // times converged restarts handed their places to the next ids of the restart queue
+    int device = -1;           // ordinal this trainer ran on (per-device entries of train_model's statistics)
 };
 
 // adds the exact-only line searches of a scope to the trainer's statistics (also when the scope unwinds)
@@ -863,25 +879,61 @@ struct QueryShard {
     uint64_t total_queries = 0;
 };
 
+// The restart ids of one request that no trainer has started yet.  The reference hands its restarts to rayon's
+// work-stealing pool (src/coordinate_ascent.rs:215-225): whichever worker is free takes the next one.  Here the workers
+// are the trainers of train_model's devices (capi.cpp, train_ca_devices): each keeps a bounded number of restarts live
+// and pulls the next id from this one counter whenever one of its restarts has converged.  Which trainer runs a restart
+// does not matter -- its trajectory depends only on its child seed (:211-213) -- so the model is the single trainer's.
+class RestartQueue {
+  public:
+    RestartQueue(uint32_t begin, uint32_t end) : next_(begin), end_(std::max(begin, end)) {}
+    bool pop(uint32_t* id) {
+        uint32_t v = next_.load(std::memory_order_relaxed);
+        while (v < end_)
+            if (next_.compare_exchange_weak(v, v + 1, std::memory_order_relaxed)) {
+                *id = v;
+                return true;
+            }
+        return false;
+    }
+    bool empty() const { return next_.load(std::memory_order_relaxed) >= end_; }
+
+  private:
+    std::atomic<uint32_t> next_;
+    const uint32_t end_;
+};
+
 class CATrainer {
   public:
     // slot / device: which device-side copy of the view this trainer runs on (DatasetView::device_ptr(slot, device);
-    // slot 0 = the view's first device form).  train_model gives every device its own trainer and restart range.
+    // slot 0 = the view's first device form).  train_model gives every device its own trainer.
+    // This form trains the fixed range [rbegin, rend), all of it live from the start.
     CATrainer(std::shared_ptr<DatasetView> view, Evaluator ev, const CAParams& p, uint32_t rbegin, uint32_t rend,
               QueryShard shard = QueryShard(), int slot = 0, int device = -1)
-        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features), shard_(std::move(shard)), slot_(slot), device_(device) {
+        : CATrainer(std::move(view), std::move(ev), p, std::make_shared<RestartQueue>(rbegin, std::min(rend, p.num_restarts)),
+                    UINT32_MAX, std::move(shard), slot, device) {}
+
+    // This form keeps at most `capacity` restarts live and takes ids from `queue` (shared with other trainers) -- at the
+    // start, and again whenever restarts of its own have converged (refill()).
+    CATrainer(std::shared_ptr<DatasetView> view, Evaluator ev, const CAParams& p, std::shared_ptr<RestartQueue> queue,
+              uint32_t capacity, QueryShard shard = QueryShard(), int slot = 0, int device = -1)
+        : view_(std::move(view)), ev_(std::move(ev)), p_(p), fids_(view_->features), shard_(std::move(shard)), slot_(slot), device_(device),
+          queue_(std::move(queue)) {
         if (fids_.empty()) fail_str("assertion failed: data.n_dim() > 0");
         if (view_->instances.empty()) fail_str("assertion failed: !data.instances().is_empty()");
         frdev::DeviceDataset& dev = view_->device(slot_, device_);
         d_ = dev.d();
         model_dim_ = *std::max_element(fids_.begin(), fids_.end()) + 1;  // :93-98
         if (model_dim_ > d_) fail_str("feature id out of range for this dataset");
-        rend = std::min(rend, p_.num_restarts);
 
         Rand64 master(p_.seed);
-        std::vector<uint64_t> child(p_.num_restarts);
-        for (uint32_t r = 0; r < p_.num_restarts; r++) child[r] = master.rand_u64();  // :211-213
-        for (uint32_t r = rbegin; r < rend; r++) rs_.emplace_back(r, child[r]);
+        child_.resize(p_.num_restarts);
+        for (uint32_t r = 0; r < p_.num_restarts; r++) child_[r] = master.rand_u64();  // :211-213
+        {
+            uint32_t id = 0;
+            while (rs_.size() < (size_t)std::max<uint32_t>(capacity, 1) && queue_->pop(&id)) rs_.emplace_back(id, child_[id]);
+        }
+        refill_min_ = std::max<size_t>(1, rs_.size() / 8);
         bool can_fused = dev.linesearch_supported(ev_.measure, ev_.depth);
         bool can_fullrank = dev.fullrank_supported(ev_.measure, ev_.depth) && !getenv("FR_FORCE_GENERIC");
         if (shard_.allreduce) {
@@ -900,29 +952,10 @@ class CATrainer {
         stats_.path = fused_ ? "fused_linesearch" : (fullrank_ ? "fused_fullrank" : "generic_sort");
         stats_.restarts = (uint32_t)rs_.size();
         if (rs_.empty()) return;
-        // initial weights + initial evaluate_mean (:104-111)
         const size_t R = rs_.size();
-        std::vector<double> w0(R * d_, 0.0);
-        for (size_t k = 0; k < R; k++) {
-            Restart& r = rs_[k];
-            r.best_w.assign(d_, 0.0);
-            if (p_.init_random) {
-                for (uint32_t f : fids_) r.best_w[f] = r.rand.rand_float() * 2.0 - 1.0;  // :50-54
-            } else {
-                for (uint32_t f : fids_) r.best_w[f] = 1.0 / (double)fids_.size();  // :60-70
-            }
-            std::copy(r.best_w.begin(), r.best_w.end(), w0.begin() + k * d_);
-        }
-        std::vector<double> means;
-        dev.set_sums_only((bool)shard_.allreduce);
-        evaluate_means_generic(dev, ev_, w0, R, means);
-        global_means(means);
-        for (size_t k = 0; k < R; k++) {
-            if (means[k] != means[k]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
-            rs_[k].best_score = means[k];
-            stats_.useful_evals++;
-            stats_.raw_evals++;
-        }
+        std::vector<size_t> all(R);
+        for (size_t k = 0; k < R; k++) all[k] = k;
+        init_restarts(all);
         // Resident base sums for the bound-and-verify kernel (device.hpp LineGroup): one slot per restart holds
         // R ~ sum_j x_j * best_w_j for every document, so a tick reads 24 bytes per document and restart instead
         // of the whole feature row.  FR_LS_RESIDENT=0 turns it off (every tick then forms the sums from the tiles).
@@ -933,24 +966,22 @@ class CATrainer {
             if (res_owner_ != 0) {
                 resident_ = true;
                 if (const char* e = getenv("FR_RESIDENT_REFRESH")) res_refresh_ = (uint32_t)std::max(1, atoi(e));
-                std::vector<size_t> all(R);
-                for (size_t k = 0; k < R; k++) {
-                    rs_[k].slot = (int)k;
-                    all[k] = k;
-                }
+                for (size_t k = 0; k < R; k++) rs_[k].slot = (int)k;
                 refresh_resident(all);
             }
         }
     }
 
+    // every restart this trainer holds has converged and the queue has no more for it
     bool done() const {
         for (const Restart& r : rs_)
             if (!r.done) return false;
-        return true;
+        return !queue_ || queue_->empty();
     }
 
     // One lock-step tick.  Returns false when every restart had already converged.
     bool tick() {
+        refill();
         frdev::DeviceDataset& dev = view_->device(slot_, device_);
         ExactTickCount etc_(dev, stats_);
         size_t gen_B = 0;
@@ -1011,84 +1042,124 @@ class CATrainer {
         frdev::DeviceDataset& dev = view_->device(slot_, device_);
         ExactTickCount etc_(dev, stats_);
         constexpr int MAXP = frdev::DeviceDataset::LINESEARCH_CONTEXTS;
-        uint64_t steps[MAXP] = {};
-        bool inflight[MAXP] = {};
-        bool ready[MAXP] = {};  // reciprocal rank: the set was evaluated in lock step (means_h_ already holds the result)
-        auto submit = [&](int h) {
-            size_t unused = 0;
-            if (steps[h] >= max_ticks || !build_groups(h, groups_h_[h], &unused)) return;
-            stats_.line_searches++;
-            dev.set_sums_only(false);
-            std::string _err;
-            ready[h] = false;
-            if (fused_) {
-                if (!dev.linesearch_ndcg_submit(h, ev_.depth, ev_.norms.data(), groups_h_[h], &_err)) fail_str(_err);
-            } else {
-                bool queued = false;
-                if (!dev.linesearch_fullrank_submit(h, ev_.measure, ev_.depth, ev_.norms.data(), groups_h_[h], &queued, &_err))
-                    fail_str(_err);
-                if (!queued) {  // not applicable this tick (the device applied the pending resident updates): exact kernels
-                    for (frdev::LineGroup& lg : groups_h_[h]) lg.has_update = false;
-                    unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
-                    dev.verify_counters(&p0, &r0);
-                    if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_h_[h], &means_h_[h], &_err))
+        // One round = the sets stepped with one line search of each in flight until the tick budget is spent, every
+        // restart has converged, or enough restarts have converged for a refill from the queue to be worth draining the
+        // pipeline (refill_wanted()); then the next round starts with the new restarts in the freed places.
+        while (n < max_ticks) {
+            refill();
+            const uint64_t budget = max_ticks - n;
+            uint64_t steps[MAXP] = {};
+            bool inflight[MAXP] = {};
+            bool ready[MAXP] = {};  // reciprocal rank: the set was evaluated in lock step (means_h_ already holds the result)
+            bool stop = false;
+            auto submit = [&](int h) {
+                size_t unused = 0;
+                if (stop || steps[h] >= budget || !build_groups(h, groups_h_[h], &unused)) return;
+                stats_.line_searches++;
+                dev.set_sums_only(false);
+                std::string _err;
+                ready[h] = false;
+                if (fused_) {
+                    if (!dev.linesearch_ndcg_submit(h, ev_.depth, ev_.norms.data(), groups_h_[h], &_err)) fail_str(_err);
+                } else {
+                    bool queued = false;
+                    if (!dev.linesearch_fullrank_submit(h, ev_.measure, ev_.depth, ev_.norms.data(), groups_h_[h], &queued, &_err))
                         fail_str(_err);
-                    dev.verify_counters(&p1, &r1);
-                    stats_.verify_pairs += p1 - p0;
-                    stats_.verify_redone += r1 - r0;
-                    ready[h] = true;
+                    if (!queued) {  // not applicable this tick (the device applied the pending resident updates): exact kernels
+                        for (frdev::LineGroup& lg : groups_h_[h]) lg.has_update = false;
+                        unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+                        dev.verify_counters(&p0, &r0);
+                        if (!dev.linesearch_fullrank(ev_.measure, ev_.depth, ev_.norms.data(), groups_h_[h], &means_h_[h], &_err))
+                            fail_str(_err);
+                        dev.verify_counters(&p1, &r1);
+                        stats_.verify_pairs += p1 - p0;
+                        stats_.verify_redone += r1 - r0;
+                        ready[h] = true;
+                    }
                 }
-            }
-            inflight[h] = true;
-        };
-        auto collect = [&](int h) {
-            std::string _err;
-            if (ready[h]) return;
-            if (fused_) {
-                if (!dev.linesearch_ndcg_collect(h, &means_h_[h], &_err)) fail_str(_err);
-            } else {
-                if (!dev.linesearch_fullrank_collect(h, &means_h_[h], &_err)) fail_str(_err);
-            }
-        };
-        auto drain = [&]() {  // an error is on its way out: leave no submitted line search behind
-            for (int h = 0; h < parts_; h++)
-                if (inflight[h] && !ready[h]) {
-                    std::string _e;
-                    std::vector<double> tmp;
-                    if (fused_) (void)dev.linesearch_ndcg_collect(h, &tmp, &_e);
-                    else (void)dev.linesearch_fullrank_collect(h, &tmp, &_e);
-                    inflight[h] = false;
+                inflight[h] = true;
+            };
+            auto collect = [&](int h) {
+                std::string _err;
+                if (ready[h]) return;
+                if (fused_) {
+                    if (!dev.linesearch_ndcg_collect(h, &means_h_[h], &_err)) fail_str(_err);
+                } else {
+                    if (!dev.linesearch_fullrank_collect(h, &means_h_[h], &_err)) fail_str(_err);
                 }
-        };
-        try {
-            for (int h = 0; h < parts_; h++) submit(h);
-            for (bool any = true; any;) {
-                any = false;
-                for (int h = 0; h < parts_; h++) {
-                    if (!inflight[h]) continue;
-                    any = true;
-                    unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
-                    dev.verify_counters(&p0, &r0);
-                    inflight[h] = false;
-                    collect(h);
-                    dev.verify_counters(&p1, &r1);
-                    stats_.verify_pairs += p1 - p0;
-                    stats_.verify_redone += r1 - r0;
-                    check_flags(dev);
-                    stats_.groups += groups_h_[h].size();
-                    apply_results(h, means_h_[h]);
-                    steps[h]++;
-                    submit(h);
+            };
+            auto drain = [&]() {  // an error is on its way out: leave no submitted line search behind
+                for (int h = 0; h < parts_; h++)
+                    if (inflight[h] && !ready[h]) {
+                        std::string _e;
+                        std::vector<double> tmp;
+                        if (fused_) (void)dev.linesearch_ndcg_collect(h, &tmp, &_e);
+                        else (void)dev.linesearch_fullrank_collect(h, &tmp, &_e);
+                        inflight[h] = false;
+                    }
+            };
+            try {
+                for (int h = 0; h < parts_; h++) submit(h);
+                for (bool any = true; any;) {
+                    any = false;
+                    for (int h = 0; h < parts_; h++) {
+                        if (!inflight[h]) continue;
+                        any = true;
+                        unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
+                        dev.verify_counters(&p0, &r0);
+                        inflight[h] = false;
+                        collect(h);
+                        dev.verify_counters(&p1, &r1);
+                        stats_.verify_pairs += p1 - p0;
+                        stats_.verify_redone += r1 - r0;
+                        check_flags(dev);
+                        stats_.groups += groups_h_[h].size();
+                        apply_results(h, means_h_[h]);
+                        steps[h]++;
+                        if (newly_done_ > 0) done_wait_++;
+                        if (refill_wanted()) stop = true;
+                        submit(h);
+                    }
                 }
+            } catch (...) {
+                drain();
+                throw;
             }
-        } catch (...) {
-            drain();
-            throw;
+            uint64_t round = 0;
+            for (int h = 0; h < parts_; h++) round = std::max(round, steps[h]);
+            n += round;
+            stats_.ticks += round;
+            if (round == 0) break;  // nothing live, nothing left to start
         }
-        for (int h = 0; h < parts_; h++) n = std::max(n, steps[h]);
-        stats_.ticks += n;
         if (ticks_done) *ticks_done = n;
         return n == max_ticks;
+    }
+
+    // Restarts that have converged hand their place (and resident slot) to the next ids of the queue: their results are
+    // kept, the new restarts get their initial weights, first evaluation and exact resident sums (init_restarts).
+    // Called with nothing in flight on the device.  Returns how many restarts were started.
+    size_t refill() {
+        newly_done_ = 0;
+        done_wait_ = 0;
+        if (!queue_ || queue_->empty()) return 0;
+        std::vector<size_t> fresh;
+        for (size_t k = 0; k < rs_.size(); k++) {
+            if (!rs_[k].done) continue;
+            uint32_t id = 0;
+            if (!queue_->pop(&id)) break;
+            finished_.push_back(result_of(rs_[k]));
+            const int slot = rs_[k].slot;
+            rs_[k] = Restart(id, child_[id]);
+            rs_[k].slot = slot;
+            fresh.push_back(k);
+        }
+        if (fresh.empty()) return 0;
+        stats_.restarts += (uint32_t)fresh.size();
+        stats_.refills++;
+        view_->device(slot_, device_).set_sums_only((bool)shard_.allreduce);
+        init_restarts(fresh);
+        if (resident_) refresh_resident(fresh);
+        return fresh.size();
     }
 
   private:
@@ -1223,6 +1294,7 @@ class CATrainer {
             if (r.pos == r.order.size()) {
                 if (r.successes == 0) {
                     r.done = true;  // :185
+                    newly_done_++;
                 } else {
                     r.pos = 0;
                     r.order.clear();
@@ -1232,15 +1304,11 @@ class CATrainer {
     }
 
   public:
+    // every restart this trainer has run or is running, in restart order
     std::vector<RestartResult> results() const {
-        std::vector<RestartResult> out;
-        for (const Restart& r : rs_) {
-            RestartResult rr;
-            rr.restart_id = r.id;
-            rr.score = r.best_score;
-            rr.weights.assign(r.best_w.begin(), r.best_w.begin() + model_dim_);
-            out.push_back(std::move(rr));
-        }
+        std::vector<RestartResult> out = finished_;
+        for (const Restart& r : rs_) out.push_back(result_of(r));
+        std::sort(out.begin(), out.end(), [](const RestartResult& a, const RestartResult& b) { return a.restart_id < b.restart_id; });
         return out;
     }
 
@@ -1248,6 +1316,36 @@ class CATrainer {
     const CAParams& params() const { return p_; }
 
   private:
+    // initial weights + initial evaluate_mean (:104-111) of the restarts rs_[which[..]]
+    void init_restarts(const std::vector<size_t>& which) {
+        frdev::DeviceDataset& dev = view_->device(slot_, device_);
+        const size_t R = which.size();
+        std::vector<double> w0(R * d_, 0.0);
+        for (size_t i = 0; i < R; i++) {
+            Restart& r = rs_[which[i]];
+            r.best_w.assign(d_, 0.0);
+            if (p_.init_random) {
+                for (uint32_t f : fids_) r.best_w[f] = r.rand.rand_float() * 2.0 - 1.0;  // :50-54
+            } else {
+                for (uint32_t f : fids_) r.best_w[f] = 1.0 / (double)fids_.size();  // :60-70
+            }
+            std::copy(r.best_w.begin(), r.best_w.end(), w0.begin() + i * d_);
+        }
+        std::vector<double> means;
+        dev.set_sums_only((bool)shard_.allreduce);
+        evaluate_means_generic(dev, ev_, w0, R, means);
+        global_means(means);
+        for (size_t i = 0; i < R; i++) {
+            if (means[i] != means[i]) fail_str("NaN found!");  // core.rs:50-55 Scored::new
+            rs_[which[i]].best_score = means[i];
+            stats_.useful_evals++;
+            stats_.raw_evals++;
+        }
+    }
+    // enough restarts have converged since the last refill (or a few have been waiting for 48 line searches), and the
+    // queue still holds ids
+    bool refill_wanted() const { return (newly_done_ >= refill_min_ || done_wait_ >= 48) && queue_ && !queue_->empty(); }
+
     // Exact resident sums for the given restarts: score_linear (ordered f64 sums of best_w) -> slot.
     void refresh_resident(const std::vector<size_t>& which) {
         frdev::DeviceDataset& dev = view_->device(slot_, device_);
@@ -1321,7 +1419,18 @@ class CATrainer {
     bool resident_ = false;
     uint64_t res_owner_ = 0;
     uint32_t res_refresh_ = 256;  // incremental updates of a resident sum between exact refreshes
+    RestartResult result_of(const Restart& r) const {
+        RestartResult rr;
+        rr.restart_id = r.id;
+        rr.score = r.best_score;
+        rr.weights.assign(r.best_w.begin(), r.best_w.begin() + model_dim_);
+        return rr;
+    }
     std::vector<Restart> rs_;
+    std::shared_ptr<RestartQueue> queue_;
+    std::vector<uint64_t> child_;           // child seeds of all num_restarts restarts, drawn in order (:211-213)
+    std::vector<RestartResult> finished_;   // restarts whose place was handed to a later one
+    size_t newly_done_ = 0, refill_min_ = 1, done_wait_ = 0;
     std::vector<frdev::LineGroup> groups_, groups_h_[frdev::DeviceDataset::LINESEARCH_CONTEXTS];
     std::vector<double> means_h_[frdev::DeviceDataset::LINESEARCH_CONTEXTS];
     int parts_ = 1;  // sets of restarts run() keeps in flight

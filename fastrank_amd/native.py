@@ -245,6 +245,18 @@ def device_plan(devices: str, device_count: int, num_restarts: int, primary_devi
     return _json_reply(_load().fr_debug_device_plan(devices.encode("utf-8"), device_count, num_restarts, primary_device))
 
 
+def restart_queue_replay(num_restarts: int, n_workers: int, capacity: int, lengths) -> Dict:
+    """The library's restart queue replayed without a device (fr_debug_restart_queue): which worker starts which restart
+    ids, in which order, when restart r converges after lengths[r % len(lengths)] ticks."""
+    arr = np.ascontiguousarray(lengths, dtype=np.uint32)
+    return _json_reply(_load().fr_debug_restart_queue(int(num_restarts), int(n_workers), int(capacity), arr.ctypes.data, len(arr)))
+
+
+def release_replicas(dataset: CDataset) -> int:
+    """Frees the copies of the dataset train_model made on other devices / in other contexts; returns how many."""
+    return int(_load().fr_dataset_release_replicas(dataset.pointer))
+
+
 def shard_bounds(num_restarts: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block partition of restart ids over ranks (first ranks take the remainder)."""
     base, rem = divmod(num_restarts, world)

@@ -146,7 +146,9 @@ void fr_ca_free(void *trainer);
 const CResult *fr_select_model(const void *restarts_json, int output_ensemble);
 /* JSON stats of the most recent train_model / fr_train_model_shard call in this process:
  * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts","verify_pairs","verify_redone",
- *  "exact_ticks","line_searches","audit_values","audit_mismatches"}
+ *  "exact_ticks","line_searches","audit_values","audit_mismatches","devices","refills"} and, after a call that ran
+ * on several devices, "per_device": the same object for every entry of the device list (its "device", "restarts",
+ * "ticks", "seconds", "refills": times converged restarts handed their places to ids from the shared restart queue)
  * (path: "fused_linesearch" | "fused_fullrank" | "generic_sort"; verify_*: (query, group) pairs evaluated by the
  * bound-and-verify kernels and how many of them were recomputed by the exact kernels; exact_ticks of line_searches
  * batched line searches went to the exact kernels alone; audit_*: with FR_VERIFY_AUDIT=1 every published NDCG@k
@@ -203,17 +205,30 @@ int fr_synchronize(void);
  * 2: the term a candidate key's error bound gains from the resident form (a = bound, b = norm, c = T).
  * No device needed.  NaN for an unknown `which`. */
 double fr_debug_resident_bound(int which, double a, double b, double c);
-/* How train_model spreads `num_restarts` coordinate-ascent restarts over the devices listed in `devices_csv` (the syntax
- * of the FR_DEVICES environment variable: comma-separated ordinals, the same ordinal twice = two contexts on that
- * device) on a node with `device_count` devices, when the dataset's first device form lives on `primary_device`:
- * JSON {"devices": [...], "slots": [...], "blocks": [[begin, end], ...]} -- contiguous blocks of restart ids, the first
- * devices take the remainder (the reference fans restarts out with rayon, src/coordinate_ascent.rs:215-225).  No device
- * needed; errors come back in the usual envelope. */
 /* Size class of the full-ranking bound-and-verify kernel (depth-less NDCG, MAP, NDCG@>20) for a query of `len` documents:
  * (keys per lane << 16) | lanes per candidate.  No device needed (the CPU tests check that every length has a class that
  * holds it and that classes grow with the length). */
 uint32_t fr_debug_fullrank_class(uint32_t len);
+/* The device plan of a request with `num_restarts` units of work (coordinate-ascent restarts, random-forest trees) over the
+ * devices listed in `devices_csv` (the syntax of the FR_DEVICES environment variable: comma-separated ordinals, the same
+ * ordinal twice = two contexts on that device) on a node with `device_count` devices, when the dataset's first device
+ * form lives on `primary_device`: JSON {"devices": [...], "slots": [...], "blocks": [[begin, end], ...]} -- which
+ * device-side copy every entry trains on and the contiguous block of ids it gets under a static partition (random
+ * forests, and coordinate ascent with FR_RESTART_QUEUE=0; by default the entries of a coordinate-ascent request pull
+ * restart ids from one shared queue instead -- the reference fans restarts out with rayon,
+ * src/coordinate_ascent.rs:215-225).  No device needed; errors come back in the usual envelope. */
 const void *fr_debug_device_plan(const void *devices_csv, int device_count, uint32_t num_restarts, int primary_device);
+/* Replays the restart queue of train_model on the CPU (no device): `n_workers` trainers with `capacity` live restarts
+ * each take the ids 0 .. num_restarts-1 from one queue; restart r is given a length of lengths[r % n_lengths] ticks and a
+ * worker refills converged places at the end of a tick.  JSON {"order": [[ids in the order worker w started them] ...],
+ * "ticks": [...]} -- the CPU tests check that every id is started exactly once and that a worker never holds more than
+ * `capacity`. */
+const void *fr_debug_restart_queue(uint32_t num_restarts, uint32_t n_workers, uint32_t capacity, const uint32_t *lengths,
+                                   uint32_t n_lengths);
+/* Frees the device-to-device copies train_model made of this dataset on other devices / in other contexts (they are kept
+ * with the dataset so that the next request reuses them; a node shared with other jobs may want the HBM back).  The
+ * dataset's first device form stays.  Returns the number of copies released. */
+size_t fr_dataset_release_replicas(const CDataset *dataset);
 
 #ifdef __cplusplus
 }

@@ -247,6 +247,30 @@ def test_in_process_device_plan_partitions_like_the_multi_process_path():
             native.device_plan(bad, 8, 32)
 
 
+def test_restart_queue_hands_every_restart_out_exactly_once():
+    """train_model's devices pull restart ids from ONE queue (the reference's rayon pool, src/coordinate_ascent.rs:215-225):
+    replayed here without a device.  Every id is started exactly once whatever the workers' speeds, a worker starts with its
+    share and never holds more than its capacity, ids come out in ascending order, and a worker whose restarts converge
+    early takes more of the rest than a slow one."""
+    rng = np.random.default_rng(5)
+    for R, workers, cap in ((256, 8, 32), (256, 8, 8), (5, 3, 2), (7, 2, 64), (1000, 8, 64), (0, 2, 4), (3, 8, 1)):
+        lengths = rng.integers(1, 40, size=max(R, 1))
+        out = native.restart_queue_replay(R, workers, cap, lengths)
+        started = [i for w in out["order"] for i in w]
+        assert sorted(started) == list(range(R)), (R, workers, cap)
+        for w, ids in enumerate(out["order"]):
+            assert ids[:cap] == sorted(ids[:cap]) and len(ids[:cap]) <= cap  # the initial share, pulled in one go
+        if R >= workers * cap:
+            assert all(len(ids) >= cap for ids in out["order"])
+    # one fast worker (its restarts take 1 tick) next to one slow one (100 ticks): the fast one ends up with most restarts
+    lengths = np.array([1 if (i // 4) % 2 == 0 else 100 for i in range(64)])
+    out = native.restart_queue_replay(64, 2, 4, lengths)
+    assert sorted(i for w in out["order"] for i in w) == list(range(64))
+    assert max(out["ticks"]) < sum(lengths) / 4  # (a static split in two blocks would leave one worker with >= half the long ones)
+    with pytest.raises(Exception, match="bad arguments"):
+        native.restart_queue_replay(4, 0, 1, [1])
+
+
 def test_fullrank_size_classes_hold_every_query_length():
     """kernels_fullverify.inc sorts a query as pl lanes of nl register-resident keys: every length up to 2048 must land in
     a class that holds it, the padding must stay small where the documents are, and a longer query never gets a

@@ -89,6 +89,51 @@ def test_fan_out_matches_the_oracle_and_handles_ensembles_and_few_restarts(data)
         o.set_mean_segment(0)
 
 
+@pytest.mark.parametrize("measure", ["ndcg@10", "map"])
+def test_restart_queue_refills_converged_places_and_keeps_the_model(data, measure, monkeypatch):
+    """The devices of a request pull restart ids from one queue (csrc/host.hpp RestartQueue, capi.cpp train_ca_devices;
+    the reference's rayon pool, src/coordinate_ascent.rs:215-225): with two places per trainer, 13 restarts go through
+    three contexts as their restarts converge -- the model, every evaluation count and the ensemble are the single
+    trainer's.  The same on ONE device: a trainer with three places runs 13 restarts three at a time."""
+    X, y, qid, g = data
+    req = _request(measure, 13)
+    one, st1 = _train(g, req, "0")
+    assert st1["refills"] == 0
+    monkeypatch.setenv("FR_RESTART_SLOTS", "2")
+    q3, st3 = _train(g, req, "0,0,0")
+    assert q3 == one
+    assert st3["devices"] == 3 and st3["restarts"] == 13 and st3["useful_evals"] == st1["useful_evals"]
+    assert st3["refills"] >= 3 and sum(d["restarts"] for d in st3["per_device"]) == 13
+    assert all(d["restarts"] >= 2 for d in st3["per_device"])
+    monkeypatch.setenv("FR_RESTART_SLOTS", "3")
+    q1, st = _train(g, req, "0")
+    assert q1 == one and st["devices"] == 1 and st["refills"] >= 3 and st["useful_evals"] == st1["useful_evals"]
+    # the static block partition of round 3 is still there (A/B switch)
+    monkeypatch.setenv("FR_RESTART_QUEUE", "0")
+    monkeypatch.delenv("FR_RESTART_SLOTS")
+    assert _train(g, req, "0,0,0")[0] == one
+    monkeypatch.delenv("FR_RESTART_QUEUE")
+    ens = _request(measure, 7, output_ensemble=True)
+    e1, _ = _train(g, ens, "0")
+    monkeypatch.setenv("FR_RESTART_SLOTS", "1")
+    assert _train(g, ens, "0,0")[0] == e1
+
+
+def test_default_device_list_keeps_small_requests_on_one_device(data):
+    """Without FR_DEVICES a device joins a request only if it would get FR_MIN_RESTARTS_PER_DEVICE restarts (and the matrix is
+    worth a copy); an explicit list is taken as given.  The copies made for a list can be released again."""
+    X, y, qid, g = data
+    req = _request("ndcg@10", 4)
+    _, st = _train(g, req, None)
+    assert st["devices"] == 1
+    _, st = _train(g, req, "0,0")
+    assert st["devices"] == 2
+    assert native.release_replicas(g) >= 1
+    assert native.release_replicas(g) == 0
+    _, st = _train(g, req, "0,0")  # (made again on demand)
+    assert st["devices"] == 2
+
+
 def test_sampled_views_are_replicated_as_views(data):
     X, y, qid, g = data
     qs = sorted(set(qid.tolist()))
