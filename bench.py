@@ -2,13 +2,18 @@
 """bench.py -- coordinate-ascent NDCG@10 evaluations/sec on an MSLR-WEB30K-shaped matrix.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  * one process per GPU (torch.distributed / RCCL when WORLD_SIZE > 1);
+  * one rank per GPU.  Under `python -m torch.distributed.run --nproc-per-node N` (WORLD_SIZE set) the ranks are
+    processes and the job's exchange is RCCL (torch.distributed, backend "nccl"; gloo if RCCL cannot start).  From a
+    plain shell with --gpus N > 1 (no launcher) the ranks are N host threads of THIS process, one per device, each
+    driving its own device-side copy of the dataset through the C ABI (ctypes releases the GIL; no PyTorch anywhere),
+    and the train-to-convergence leg goes through the library's own train_model fan-out (FR_DEVICES, one shared
+    restart queue) -- `--launcher torch` re-executes the script under torch.distributed.run instead;
   * a STEP is one lock-step coordinate-ascent tick: one fused HIP launch that evaluates every
     line-search candidate (1 + 2*25 = 51) of every live restart on this GPU (32 restarts per
     GPU -> 1632 reference `evaluate_mean` results per step), plus the host replay of the
     reference's sequential accept/early-break logic;
-  * W untimed steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize();
-    time = max over ranks; value = useful evaluations of all ranks / time;
+  * W untimed steps, then exactly K timed steps bracketed by barrier + device synchronize (torch.cuda.synchronize()
+    where torch is loaded); time = max over ranks; value = useful evaluations of all ranks / time;
   * weak scaling (default): 32 restarts per GPU (BASELINE.json configs[2] at N=1, configs[3] at N=8),
     dataset replicated, restarts block-partitioned, no data-path collective;
     strong scaling (--restarts-total R): one fixed job of R restarts split over the ranks.
@@ -110,10 +115,10 @@ def gen_mslr_shaped(seed, n, d, q, kind="mslr"):
     return X, y, qid
 
 
-def source_sha1():
+def source_sha1(names=None):
     """SHA-1 of the kernel / trainer sources the PMC constants depend on."""
     out = {}
-    for name in PMC_SOURCES:
+    for name in (names or PMC_SOURCES):
         path = os.path.join(ROOT, "fastrank_amd", "csrc", name)
         out[name] = hashlib.sha1(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
     return out
@@ -133,32 +138,174 @@ def random_trees(rng, X, ntrees, max_depth):
     return [grow(1) for _ in range(ntrees)]
 
 
-def bench_trees(args, world, rank, dist, fr, native, dataset, X, y, qid, n, d):
+class SingleComm:
+    """One rank, no exchange.  `torch` is used only for torch.cuda.synchronize() (the contract's bracket)."""
+    world, rank, backend = 1, 0, "none"
+
+    def __init__(self, torch_mod=None):
+        self.torch = torch_mod
+
+    def barrier(self):
+        pass
+
+    def sync_device(self):
+        from fastrank_amd import native
+        native.synchronize()
+        if self.torch is not None:
+            self.torch.cuda.synchronize()
+
+    def allreduce(self, values, op):
+        return list(values)
+
+    def allgather_rows(self, row):
+        return [list(row)]
+
+    def gather_restarts(self, mine, num_restarts):
+        return sorted(mine, key=lambda r: r["restart_id"])
+
+    def steal_blocks(self, num_restarts, block):
+        for b in range(0, num_restarts, block):
+            yield b, min(num_restarts, b + block)
+
+    def close(self):
+        pass
+
+
+class TorchComm(SingleComm):
+    """One process per GPU under torch.distributed.run; RCCL (backend "nccl") unless it cannot start, then gloo --
+    the data path has no collective either way (barriers, three small reductions, one all-gather of restart records)."""
+
+    def __init__(self, torch_mod, dist, backend, device):
+        self.torch, self.dist, self.backend = torch_mod, dist, backend
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.dev = device if backend == "nccl" else torch_mod.device("cpu")
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def allreduce(self, values, op):
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
+    def allgather_rows(self, row):
+        t = self.torch.tensor(list(row), dtype=self.torch.float64, device=self.dev)
+        parts = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [x.cpu().tolist() for x in parts]
+
+    def gather_restarts(self, mine, num_restarts):
+        from fastrank_amd import native
+        return native.gather_restarts(mine, num_restarts)
+
+    def steal_blocks(self, num_restarts, block):
+        from fastrank_amd import native
+        return native.steal_blocks(num_restarts, block)
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+class ThreadHub:
+    """What the N rank threads of one process share: a barrier, a slot per rank, a counter."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.lock = threading.Lock()
+        self.counters = {}
+
+
+class ThreadComm(SingleComm):
+    """Rank = host thread of this process, one per device (no launcher, no PyTorch): exchanges go through host memory."""
+    backend = "threads"
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world, self.torch = hub, rank, hub.world, None
+        self._jobs = 0
+
+    def barrier(self):
+        self.hub.bar.wait()
+
+    def _exchange(self, item):
+        self.hub.slots[self.rank] = item
+        self.hub.bar.wait()
+        got = list(self.hub.slots)
+        self.hub.bar.wait()  # nobody overwrites a slot before everybody has read it
+        return got
+
+    def allreduce(self, values, op):
+        rows = self._exchange(list(values))
+        return [max(col) if op == "max" else sum(col) for col in zip(*rows)]  # (sum: in rank order on every rank)
+
+    def allgather_rows(self, row):
+        return [list(r) for r in self._exchange(list(row))]
+
+    def gather_restarts(self, mine, num_restarts):
+        allr = sorted((r for part in self._exchange(list(mine)) for r in part), key=lambda r: r["restart_id"])
+        if [r["restart_id"] for r in allr] != list(range(num_restarts)):
+            raise RuntimeError("gather_restarts: expected restarts 0..{} exactly once".format(num_restarts - 1))
+        return allr
+
+    def steal_blocks(self, num_restarts, block):
+        key = self._jobs
+        self._jobs += 1
+        while True:
+            with self.hub.lock:
+                k = self.hub.counters.get(key, 0)
+                self.hub.counters[key] = k + 1
+            if k * block >= num_restarts:
+                return
+            yield k * block, min(num_restarts, (k + 1) * block)
+
+
+TREE_PMC_SOURCES = ("kernels_treerank.inc", "kernels_tree.inc", "device_dataset.inc")
+
+
+def load_tree_pmc(shape):
+    """rocprofv3 --pmc figures of the tree-scoring kernel (profiles/hbm_traffic.json[shape]["trees"], captured by
+    tools/pmc_trees.sh on `bench.py --measure trees`): static, tied to the SHA-1 of the kernel sources, `stale` when the
+    sources built here differ."""
+    meta = {"source": "profiles/hbm_traffic.json[{}][trees] (rocprofv3 --pmc passes over `python bench.py --measure trees`, "
+                      "tools/pmc_trees.sh); static, not measured in this run".format(shape),
+            "current_sha1": source_sha1(TREE_PMC_SOURCES)}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(shape, {}).get("trees") or {}
+    except Exception as exc:
+        meta.update({"stale": True, "note": "unreadable: {}".format(exc)})
+        return {}, meta
+    cap = tj.get("captured") or {}
+    meta["captured_sha1"], meta["captured_round"] = cap.get("sha1"), cap.get("round")
+    meta["stale"] = (not tj) or cap.get("sha1") != meta["current_sha1"]
+    return tj, meta
+
+
+def bench_trees(args, comm, fr, native, dataset, X, y, qid, n, d):
     """BASELINE.json configs[4] as a bench line (`--measure trees`): one step = one 500-tree ensemble pass over the
     30K shape with the batched tree-traversal kernel.  Ranks score replicas of the same matrix (document shards of one
     pass would be the production split; no exchange either way), so N > 1 is weak scaling over replicas."""
-    import torch
-
+    world, rank = comm.world, comm.rank
     trees = random_trees(np.random.default_rng(7), X, 500, 8)
     model = fr.CModel.from_dict({"Ensemble": {"weights": [1.0] * len(trees), "models": [{"DecisionTree": t} for t in trees]}})
-    out = None
     for _ in range(max(1, args.warmup)):
-        out = native.predict_scores_dense(model, dataset, 0)  # (0 rows copied back: the pass itself)
-    native.synchronize()
-    if world > 1:
-        dist.barrier()
-    native.profile_reset()
-    native.profile_enable(True)
+        native.predict_scores_dense(model, dataset, 0)  # (0 rows copied back: the pass itself)
+    comm.barrier()
+    comm.sync_device()
+    if rank == 0:
+        native.profile_reset()
+        native.profile_enable(True)
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         native.predict_scores_dense(model, dataset, 0)
-    native.synchronize()
+    comm.barrier()
+    comm.sync_device()
     elapsed = time.perf_counter() - t0
     native.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = comm.allreduce([elapsed], "max")[0]
     if rank != 0:
         return
     stats = native.profile_stats()
@@ -171,19 +318,30 @@ def bench_trees(args, world, rank, dist, fr, native, dataset, X, y, qid, n, d):
     ok = bool(np.array_equal(o.Dataset(X[:m], y[:m], qid[:m]).score_ensemble(trees, [1.0] * len(trees)), got))
     b_rf = n * (4 * d + 8)  # read X once, write one f64 score per document
     sec = k["avg_ms"] * 1e-3
+    tj, pmc_meta = load_tree_pmc(args.shape)
+    traffic = tj.get("bytes_per_pass")
+    slots = N_SIMD * CLOCK_HZ * sec
+    limiter = {"bound": "valu_issue + lds", "unit": "fraction of 1024 SIMDs x 2.4 GHz issue cycles",
+               "frac": (tj["valu_insts_per_pass"] * 4.0 / slots) if tj.get("valu_insts_per_pass") else None,
+               "lds_insts_per_pass": tj.get("lds_insts_per_pass"),
+               "valu_active_frac_of_busy_cycles": tj.get("valu_active_frac_of_busy_cycles"),
+               "lds_address_unit_busy_frac_of_busy_cycles": tj.get("lds_idx_active_frac_of_busy_cycles"),
+               "lds_bank_conflict_frac_of_lds_active": tj.get("lds_bank_conflict_frac_of_lds_active"),
+               "clock_ghz_under_load": tj.get("clock_ghz")}
     print(json.dumps({
         "metric": "tree-ensemble scoring passes/sec on MSLR-WEB30K shape (BASELINE.json configs[4])",
         "value": world * args.steps / elapsed, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "500 random trees of depth <= 8 x %d docs x %d features (configs[4]); one step = one ensemble pass" % (n, d),
-                   "parallelism": "replicas x{}".format(world)},
+                   "parallelism": "replicas x{}".format(world), "launcher": comm.backend},
         "doc_trees_per_s": world * n * len(trees) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": b_rf / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": b_rf / sec / 1e9 / HBM_PEAK_GBS, "traffic": 2.17e9, "kernel": kname, "avg_launch_ms": k["avg_ms"],
-                     "note": "traffic: FETCH_SIZE x2 + WRITE_SIZE of profiles/r02_pmc_treerank_after_summary.txt (static)"},
-        "limiter": {"bound": "valu_issue + lds", "frac": 0.61, "lds_address_unit_busy": 0.63,
-                    "source": "profiles/r02_pmc_treerank_after_summary.txt (static, round 2: the kernel is unchanged)"},
+                     "frac": b_rf / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname, "avg_launch_ms": k["avg_ms"],
+                     "hbm_frac_measured": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "note": "traffic: (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 per pass from the PMC capture named in `pmc` (null when none)"},
+        "limiter": limiter,
+        "pmc": pmc_meta,
         "parity_first_docs_bit_exact": ok,
     }))
 
@@ -215,8 +373,8 @@ def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
     cores: threads over restarts only, like rayon in the reference.  Bounded sample."""
     from oracle import pyoracle as o
 
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    cores = os.cpu_count() or 1          # the node's logical cores (SURVEY 8d: stated next to the number)
+    threads = max(1, min(cores, 64))     # threads the port actually used: one per restart, like rayon over restarts
     ds = o.Dataset(X, y, qid)
     p = dict(params)
     p["num_restarts"] = threads
@@ -236,7 +394,8 @@ def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
     return {
         "value": n2 / t2,
         "unit": "evals/s",
-        "cores": threads,
+        "cores": cores,
+        "threads": threads,
         "kind": "port",
         "sample": "{} restarts x {} evaluate_mean calls each of the same CA run ({} evals in {:.1f} s); "
                   "oracle/fastrank_oracle.c, per-call query regrouping hoisted".format(threads, m, n2, t2),
@@ -244,10 +403,10 @@ def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--measure", default="ndcg@10", help="headline = ndcg@10 (BASELINE.json); others (ndcg, map, mrr, ndcg@k) for side measurements")
+    ap.add_argument("--measure", default="ndcg@10", help="headline = ndcg@10 (BASELINE.json); others (ndcg, map, mrr, ndcg@k, trees) for side measurements")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shape", default=os.environ.get("FR_BENCH_SHAPE", "30k"), choices=sorted(SHAPES))
@@ -260,50 +419,146 @@ def main():
                     help="e2e leg: ranks pull blocks of this many restarts from a shared counter (0 = static block partition)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the train-to-convergence leg")
     ap.add_argument("--inprocess-devices", default=os.environ.get("FR_BENCH_INPROCESS", ""),
-                    help="single process only: also train the e2e job through the library's own train_model with FR_DEVICES set "
-                         "to this list (e.g. 0,1,2,3,4,5,6,7, or 0,0 for two contexts on one GPU): the in-process fan-out a caller "
-                         "of the reference's API gets, next to the one-process-per-GPU numbers")
+                    help="also train the e2e job through the library's own train_model with FR_DEVICES set to this list (e.g. "
+                         "0,1,2,3,4,5,6,7, or 0,0 for two contexts on one GPU): the in-process fan-out a caller of the reference's "
+                         "API gets.  With --launcher threads it defaults to the ranks' devices")
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (default); gloo only for single-GPU smoke tests of the N>1 path")
-    args = ap.parse_args()
+                    help="torch launcher: nccl = RCCL over xGMI (default; falls back to gloo if it cannot start); gloo for "
+                         "single-GPU smoke tests of the N>1 path")
+    ap.add_argument("--launcher", default=os.environ.get("FR_BENCH_LAUNCHER", "auto"), choices=["auto", "torch", "threads"],
+                    help="auto: the ranks torch.distributed.run started when WORLD_SIZE is set, otherwise N host threads of this "
+                         "process (one per device, no PyTorch); torch: re-execute under torch.distributed.run when no launcher "
+                         "started this process; threads: always threads")
+    return ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    # FR_BENCH_DEVICE pins every rank to one ordinal (2-rank smoke test of the N>1 path on a 1-GPU box)
-    dev_ordinal = int(os.environ.get("FR_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_ordinal)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_ordinal))
-        else:
-            dist.init_process_group(backend="gloo")
-    coll_dev = torch.device("cuda", dev_ordinal) if args.backend == "nccl" else torch.device("cpu")
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
+def main():
+    args = parse_args()
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    launcher = args.launcher
+    if launcher == "auto":
+        launcher = "torch" if env_world > 0 else ("threads" if args.gpus > 1 else "single")
+    if launcher == "torch" and env_world == 0:
+        if args.gpus == 1:
+            launcher = "single"
+        else:  # a plain shell asked for the one-process-per-GPU form: start it the way the driver does
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            os.execv(sys.executable, cmd)
+    if launcher == "threads" and args.gpus == 1:
+        launcher = "single"
 
     import fastrank_amd as fr
     from fastrank_amd import native
 
-    native.set_device(dev_ordinal)
     n, d, q, seed = SHAPES[args.shape]
+    if launcher == "threads":
+        run_threads(args, fr, native)
+        return
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FR_BENCH_DEVICE pins every rank to one ordinal (2-rank smoke test of the N>1 path on a 1-GPU box)
+    dev_ordinal = int(os.environ.get("FR_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_ordinal)
+    if launcher == "torch":
+        import datetime
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend, note = args.backend, None
+        if backend == "nccl":
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_ordinal), timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", dev_ordinal))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:  # RCCL could not start on this node: the job has no data-path collective, gloo carries the rest
+                note = "nccl (RCCL) failed to start: {}: {}; using gloo".format(type(exc).__name__, str(exc)[:200])
+                print("[bench.py] " + note, file=sys.stderr, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"  # (same rendezvous: under torch.distributed.run the launcher's agent hosts the store)
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+        comm = TorchComm(torch, dist, backend, torch.device("cuda", dev_ordinal))
+        comm.note = note
+        if comm.world != args.gpus:
+            raise SystemExit("bench.py --gpus {} was started with WORLD_SIZE={}: launch with torch.distributed.run "
+                             "--nproc-per-node {} (or from a plain shell, which starts its own ranks)".format(args.gpus, comm.world, args.gpus))
+    else:
+        comm = SingleComm(torch)
+    native.set_device(dev_ordinal)
     t0 = time.perf_counter()
     X, y, qid = gen_mslr_shaped(seed, n, d, q, args.data)
     gen_s = time.perf_counter() - t0
+    try:
+        rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, None)
+    finally:
+        comm.close()
+
+
+def run_threads(args, fr, native):
+    """--gpus N from a plain shell: N rank threads of this process, one per device (FR_BENCH_DEVICE pins all of them to
+    one ordinal: N contexts on one GPU, the smoke test of this path on a one-GPU box)."""
+    import threading
+
+    if native.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    pin = os.environ.get("FR_BENCH_DEVICE")
+    devices = [int(pin)] * args.gpus if pin is not None else list(range(args.gpus))
+    if max(devices) >= native.device_count():
+        raise SystemExit("bench.py --gpus {}: only {} device(s) visible (FR_BENCH_DEVICE=k puts every rank on device k)".format(
+            args.gpus, native.device_count()))
+    n, d, q, seed = SHAPES[args.shape]
+    t0 = time.perf_counter()
+    X, y, qid = gen_mslr_shaped(seed, n, d, q, args.data)  # one host copy, borrowed by every rank's dataset
+    gen_s = time.perf_counter() - t0
+    hub = ThreadHub(args.gpus)
+    errors = []
+
+    def body(rank):
+        try:
+            native.set_device(devices[rank])
+            rank_main(args, ThreadComm(hub, rank), fr, native, X, y, qid, gen_s, devices[rank], devices)
+        except BaseException as exc:  # release the other ranks from their barriers, then report
+            errors.append((rank, exc))
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=body, args=(r,), name="rank%d" % r) for r in range(args.gpus)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    real = [(r, e) for r, e in errors if not isinstance(e, threading.BrokenBarrierError)] or errors
+    if real:
+        rank, exc = real[0]
+        raise SystemExit("bench.py rank {} failed: {}: {}".format(rank, type(exc).__name__, exc))
+
+
+def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devices):
+    """What one rank does (a process under torch.distributed.run, or a host thread of this process)."""
+    world, rank = comm.world, comm.rank
+    n, d = X.shape
+    q = SHAPES[args.shape][2]
     dataset = fr.CDataset.from_numpy(X, y, qid)
 
     if args.measure == "trees":
-        bench_trees(args, world, rank, dist, fr, native, dataset, X, y, qid, n, d)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        bench_trees(args, comm, fr, native, dataset, X, y, qid, n, d)
         return
 
     strong = args.restarts_total > 0
@@ -315,24 +570,16 @@ def main():
     p.tolerance, p.normalize, p.init_random, p.seed, p.quiet = 0.001, True, True, 42, True
     begin, end = native.shard_bounds(R, rank, world)
     my_restarts = end - begin
+    solo = rank == 0  # legs that use process-wide switches (HIP-event instrumentation, FR_LS_PIPELINE) run on rank 0 alone when the ranks are threads
+    threads_mode = thread_devices is not None
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def allgather_rows(row):
-        """[world][len(row)] float64 table of one small row per rank (reporting only)."""
-        t = torch.tensor(row, dtype=torch.float64, device=coll_dev)
-        if world == 1:
-            return [t.cpu().tolist()]
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)
-        return [x.cpu().tolist() for x in parts]
+        comm.barrier()
+        comm.sync_device()
 
     t0 = time.perf_counter()
     run = native.CoordinateAscentRun(dataset, req, begin, end)  # uploads + initial evaluate_mean per restart
-    torch.cuda.synchronize()
+    comm.sync_device()
     upload_s = time.perf_counter() - t0
 
     totals = {"useful_evals": 0, "raw_evals": 0, "verify_pairs": 0, "verify_redone": 0, "exact_ticks": 0, "ticks": 0,
@@ -369,59 +616,56 @@ def main():
     # launch: ~50 us of host time per set and tick, which is on the critical path of the pipeline -- FR_BENCH_PROFILE_TIMED=1
     # puts it back); the per-kernel numbers come from two instrumented legs right after it, which are not part of `value`.
     profile_timed = os.environ.get("FR_BENCH_PROFILE_TIMED", "0") == "1"
-    native.profile_reset()
-    native.profile_enable(profile_timed)
+    if solo:
+        native.profile_reset()
+        native.profile_enable(profile_timed)
     barrier()
     t0 = time.perf_counter()
     advance(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    native.profile_enable(False)
-    s1 = snapshot()
-    if profile_timed:
-        prof, prof_steps, prof_raw = native.profile_stats(), args.steps, s1["raw_evals"] - s0["raw_evals"]
-    else:  # the same pipelined stepping, instrumented (overlapping launches: durations of the sets' kernels in flight together)
-        prof_steps = max(1, min(args.steps, 10))
-        native.profile_reset()
-        native.profile_enable(True)
-        advance(prof_steps)
-        torch.cuda.synchronize()
+    if solo:
         native.profile_enable(False)
-        prof = native.profile_stats()
-        prof_raw = snapshot()["raw_evals"] - s1["raw_evals"]
-    # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
-    # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
-    # step, nothing else on the device) give the duration of an ISOLATED launch: the roofline object below is computed
-    # from it.  They are not part of `value`.  (tools/pmc_bench.sh counts the instructions and HBM bytes of both kinds
-    # of launches of this same command.)
-    iso = None
-    iso_evals = 0
-    ISO_STEPS = 4
-    if not os.environ.get("FR_LS_PIPELINE"):
-        os.environ["FR_LS_PIPELINE"] = "0"
-        try:
-            i0 = snapshot()
+    s1 = snapshot()
+    prof, prof_steps, prof_raw, iso, iso_evals = {}, 0, 0, None, 0
+    if solo or not threads_mode:
+        if profile_timed:
+            prof, prof_steps, prof_raw = native.profile_stats(), args.steps, s1["raw_evals"] - s0["raw_evals"]
+        else:  # the same pipelined stepping, instrumented (overlapping launches: durations of the sets' kernels in flight together)
+            prof_steps = max(1, min(args.steps, 10))
             native.profile_reset()
             native.profile_enable(True)
-            advance(ISO_STEPS)
-            torch.cuda.synchronize()
+            advance(prof_steps)
+            comm.sync_device()
             native.profile_enable(False)
-            iso = native.profile_stats()
-            iso_evals = snapshot()["raw_evals"] - i0["raw_evals"]
-        finally:
-            del os.environ["FR_LS_PIPELINE"]
+            prof = native.profile_stats()
+            prof_raw = snapshot()["raw_evals"] - s1["raw_evals"]
+        # The timed steps keep several launches of the dominant kernel in flight (the restarts are stepped as three sets
+        # on three streams), so their HIP-event durations overlap.  A few more steps in plain lock step (one launch per
+        # step, nothing else on the device) give the duration of an ISOLATED launch: the roofline object below is computed
+        # from it.  They are not part of `value`.  (tools/pmc_bench.sh counts the instructions and HBM bytes of both kinds
+        # of launches of this same command.)
+        ISO_STEPS = 4
+        if not os.environ.get("FR_LS_PIPELINE"):
+            os.environ["FR_LS_PIPELINE"] = "0"
+            try:
+                i0 = snapshot()
+                native.profile_reset()
+                native.profile_enable(True)
+                advance(ISO_STEPS)
+                comm.sync_device()
+                native.profile_enable(False)
+                iso = native.profile_stats()
+                iso_evals = snapshot()["raw_evals"] - i0["raw_evals"]
+            finally:
+                del os.environ["FR_LS_PIPELINE"]
+    if threads_mode:
+        comm.barrier()  # (the other rank threads wait here while rank 0 runs its instrumented legs)
 
     useful = s1["useful_evals"] - s0["useful_evals"]
     raw = s1["raw_evals"] - s0["raw_evals"]
-    tvals = torch.tensor([elapsed, float(useful), float(raw)], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        tmax = tvals.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tvals.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, useful_all, raw_all = float(tmax[0]), float(tsum[1]), float(tsum[2])
-    else:
-        elapsed_max, useful_all, raw_all = elapsed, float(useful), float(raw)
+    elapsed_max = comm.allreduce([elapsed], "max")[0]
+    useful_all, raw_all = comm.allreduce([float(useful), float(raw)], "sum")
     best_so_far = max(r["score"] for r in run.state()["restarts"]) if my_restarts else float("nan")
     run.close()
 
@@ -432,7 +676,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         mine, blocks, ticks, e_stats = [], [], 0, dict.fromkeys(totals, 0)
-        chunks = native.steal_blocks(R, args.steal_block) if args.steal_block > 0 else ([(begin, end)] if my_restarts else [])
+        chunks = comm.steal_blocks(R, args.steal_block) if args.steal_block > 0 else ([(begin, end)] if my_restarts else [])
         for b, e in chunks:
             job = native.CoordinateAscentRun(dataset, req, b, e)
             while not job.finished:
@@ -443,22 +687,23 @@ def main():
             blocks.append([b, e])
             for k in e_stats:
                 e_stats[k] += int(st["stats"].get(k, 0) or 0)
-        torch.cuda.synchronize()
+        comm.sync_device()
         busy_s = time.perf_counter() - t0
-        allr = native.gather_restarts(mine, R) if world > 1 else sorted(mine, key=lambda r: r["restart_id"])
+        allr = comm.gather_restarts(mine, R)
         model = native.select_model(allr, False)
         barrier()
         e2e_s = time.perf_counter() - t0
-        rows = allgather_rows([float(ticks), busy_s, float(e_stats["useful_evals"]), float(e_stats["raw_evals"]),
-                               float(len(mine)), float(e_stats["verify_pairs"]), float(e_stats["verify_redone"]),
-                               float(e_stats["exact_ticks"]), e2e_s, float(e_stats["line_searches"])])
+        rows = comm.allgather_rows([float(ticks), busy_s, float(e_stats["useful_evals"]), float(e_stats["raw_evals"]),
+                                    float(len(mine)), float(e_stats["verify_pairs"]), float(e_stats["verify_redone"]),
+                                    float(e_stats["exact_ticks"]), e2e_s, float(e_stats["line_searches"])])
         wall = max(r[8] for r in rows)
         busy = [r[1] for r in rows]
         best = max(allr, key=lambda r: r["score"])
         e2e = {
-            "what": "one job of {} restarts trained to convergence, all-gather of (restart, score, weights) and last-max "
+            "what": "one job of {} restarts trained to convergence, {} of (restart, score, weights) and last-max "
                     "selection included (time-to-model); {}".format(
-                        R, "work stealing in blocks of {}".format(args.steal_block) if args.steal_block > 0 else "static block partition"),
+                        R, {"nccl": "RCCL all-gather", "gloo": "gloo all-gather", "threads": "gather in host memory", "none": "no exchange (one rank)"}[comm.backend],
+                        "work stealing in blocks of {}".format(args.steal_block) if args.steal_block > 0 else "static block partition"),
             "wall_s": wall,
             "useful_evals": sum(r[2] for r in rows),
             "e2e_evals_per_s": sum(r[2] for r in rows) / wall,
@@ -476,12 +721,15 @@ def main():
     else:
         e2e_top = None
 
-    # ---- optional third leg: the same job through train_model itself, fanned out inside the library over FR_DEVICES ----
+    # ---- third leg: the same job through train_model itself, fanned out inside the library over FR_DEVICES (one shared
+    #      restart queue, one host thread + trainer + device-to-device dataset copy per entry); with the thread launcher this
+    #      is the product's own multi-GPU path over the ranks' devices, run by rank 0 while the other ranks wait
     inproc = None
-    if args.inprocess_devices and world == 1:
+    inproc_list = args.inprocess_devices or (",".join(str(x) for x in thread_devices) if threads_mode and not args.no_e2e else "")
+    if inproc_list and rank == 0 and (world == 1 or threads_mode):
         p.seed = 42
         old_env = os.environ.get("FR_DEVICES")
-        os.environ["FR_DEVICES"] = args.inprocess_devices
+        os.environ["FR_DEVICES"] = inproc_list
         try:
             runs = []
             for attempt in range(2):  # the first call also makes the device-to-device copies of the dataset
@@ -489,18 +737,26 @@ def main():
                 m2 = dataset.train_model(req)
                 wall = time.perf_counter() - t0
                 st = native.last_train_stats()
+                per_dev = st.get("per_device") or []
+                secs = [x["seconds"] for x in per_dev]
                 runs.append({"wall_s": wall, "useful_evals": st["useful_evals"], "e2e_evals_per_s": st["useful_evals"] / wall,
-                             "devices": st["devices"], "ticks_longest_device": st["ticks"]})
+                             "devices": st["devices"], "ticks_longest_device": st["ticks"], "refills": st.get("refills"),
+                             "per_device_ticks": [x["ticks"] for x in per_dev], "per_device_restarts": [x["restarts"] for x in per_dev],
+                             "per_device_busy_s": secs,
+                             "idle_fraction": (1.0 - (sum(secs) / len(secs)) / max(max(secs), 1e-12)) if secs else None})
             sha = hashlib.sha1(json.dumps(m2.to_dict(), sort_keys=True).encode()).hexdigest()
-            inproc = {"what": "dataset.train_model(request) with FR_DEVICES={}: restarts block-partitioned over the listed devices "
-                              "inside the call, one host thread + trainer + device-to-device dataset copy each".format(args.inprocess_devices),
+            inproc = {"what": "dataset.train_model(request) with FR_DEVICES={}: the listed devices pull the {} restarts from one queue "
+                              "inside the call, one host thread + trainer + device-to-device dataset copy each".format(inproc_list, R),
                       "first_call_with_replication": runs[0], "second_call": runs[1], "model_sha1": sha,
-                      "same_model_as_e2e_leg": (e2e is not None and sha == e2e["model_sha1"]) if e2e is not None else None}
+                      "same_model_as_e2e_leg": (sha == e2e["model_sha1"]) if e2e is not None else None}
+            native.release_replicas(dataset)
         finally:
             if old_env is None:
                 del os.environ["FR_DEVICES"]
             else:
                 os.environ["FR_DEVICES"] = old_env
+    if threads_mode:
+        comm.barrier()
 
     if rank == 0:
         b_eval = n * (4 * d + 8)  # algorithmic bytes per evaluate_mean
@@ -644,6 +900,9 @@ def main():
                                 1 if args.shape == "10k" else (3 if R == 256 and world == 8 else 2)),
                 "restarts_total": R,
                 "parallelism": "restart-sharded x{} (dataset replicated)".format(world),
+                "launcher": {"none": "single process", "threads": "one host thread per device in one process (no PyTorch)"}.get(
+                    comm.backend, "torch.distributed.run, backend {}".format(comm.backend)),
+                "collective_note": getattr(comm, "note", None),
                 "evals_per_step_per_gpu": evals_per_step,
                 "launches_per_step": ls["launches"] / max(1, prof_steps),
                 "groups_per_launch": groups_per_launch,
@@ -677,9 +936,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds, args.measure)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -66,7 +66,10 @@ static constexpr int FV_BLOCK_WAVES = 4;  // waves per workgroup
 #ifndef FV_WPS64
 #define FV_WPS64 2
 #endif
-constexpr int fv_waves_per_simd(int nl) { return nl <= 16 ? 5 : (nl <= 32 ? 4 : (nl <= 48 ? 3 : (nl <= 64 ? FV_WPS64 : 2))); }
+#ifndef FV_WPS96
+#define FV_WPS96 2
+#endif
+constexpr int fv_waves_per_simd(int nl) { return nl <= 16 ? 5 : (nl <= 32 ? 4 : (nl <= 48 ? 3 : (nl <= 64 ? FV_WPS64 : (nl <= 80 ? 2 : FV_WPS96)))); }
 
 // LDS of one workgroup (bytes): the words of 2 x qb queries, the records of the nrec queries the block walks, the
 // candidate table, the term table.  tab_doubles = doubles of the metric's table in LDS (0: terms are gathered from global memory).
