@@ -53,6 +53,7 @@ namespace frdev {
 #include "kernels_treerank.inc"
 #include "kernels_metric.inc"
 #include "kernels_linesearch.inc"
+#include "kernels_chain.inc"
 #include "kernels_verify.inc"
 #include "kernels_fullrank.inc"
 #include "kernels_rr.inc"

@@ -99,16 +99,75 @@ def chains_lazy(keys, y, starts):
     return runs / docs, events / docs
 
 
+def chains_primed(keys, y, starts, base_key, xf, with_xf, kprime=K):
+    """every lane's list is first filled with the keys of a PRIMING SET of the query's documents -- the
+    kprime best under the restart's current weights (= what the previous tick's accepted candidate ranked first), optionally
+    also the K documents with the largest and the K with the smallest x_f (what the extreme candidates rank first) -- by
+    running the chain for each of them; the main pass then skips those documents and admits against thresholds that are
+    already high.  Any priming set is safe (a wrong one only admits more).  Returns (chains per document incl. the priming
+    inserts, priming documents per document, admitted-after-priming chains per document)."""
+    docs = runs = primed = 0
+    for qi in range(len(starts) - 1):
+        idx = storage_order(y, starts[qi], starts[qi + 1])
+        kk = keys[idx]
+        n = len(idx)
+        S = set(np.argsort(-base_key[idx], kind="stable")[:kprime].tolist())
+        if with_xf:
+            o = np.argsort(xf[idx], kind="stable")
+            S |= set(o[:K].tolist()) | set(o[-K:].tolist())
+        S = sorted(S)
+        L = np.full((keys.shape[1], K), -np.inf)
+        for t in S:  # priming: one chain per document, no test
+            for c in range(keys.shape[1]):
+                if kk[t, c] >= L[c, -1]:
+                    L[c, -1] = kk[t, c]
+                    L[c][::-1].sort()
+        primed += len(S)
+        inS = np.zeros(n, bool)
+        inS[S] = True
+        for t in range(n):
+            if inS[t]:
+                continue
+            a = kk[t] >= L[:, -1]
+            if a.any():
+                runs += 1
+                for c in np.nonzero(a)[0]:
+                    L[c, -1] = kk[t, c]
+                    L[c][::-1].sort()
+        docs += n
+    return (runs + primed) / docs, primed / docs, runs / docs
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["pack", "lazy"], default="pack")
+    ap.add_argument("--mode", choices=["pack", "lazy", "prime"], default="pack")
     ap.add_argument("--docs", type=int, default=40000)
     ap.add_argument("--queries", type=int, default=330)
     args = ap.parse_args()
     X, y, qid = bench.gen_mslr_shaped(20250929, args.docs, 136, args.queries)
     starts = np.r_[0, np.nonzero(np.diff(qid))[0] + 1, len(qid)]
     k1, k2 = keys_of(X, 1, 3), keys_of(X, 2, 42)
-    if args.mode == "pack":
+    if args.mode == "prime":
+        # per-document wave-instructions of the kernel: 3 (phase S) + 4.5 (word read, FMA, class insert, admission test) + 13 per
+        # chain (the measured 10.4 at 0.45 chains per document, DESIGN 4d); priming adds a gather of the priming words (~2 per primed document)
+        def insts(chains, primed=0.0):
+            return 7.5 + 13.0 * chains + 2.0 * primed
+        for name, seed, f in (("feature 3 (sparse column)", 1, 3), ("feature 42 (heavy tail)", 2, 42), ("feature 8 (signal, uniform)", 3, 8), ("feature 5 (integer, ties)", 4, 5)):
+            r = np.random.default_rng(seed)
+            w = r.uniform(-1, 1, 136) * 0.2
+            w[::8] += 1.0
+            w /= np.abs(w).sum()
+            base = X.astype(np.float64) @ w
+            xf = X[:, f].astype(np.float64)
+            keys = (base - xf * w[f])[:, None] + xf[:, None] * cands(w[f])[None, :]
+            e, _ = chains_eager(keys, y, starts)
+            p1 = chains_primed(keys, y, starts, base, xf, False)
+            p2 = chains_primed(keys, y, starts, base, xf, True)
+            print("%-28s chains per document: now %.3f | primed with the current top-%d %.3f (priming %.3f + admitted %.3f) | + top / bottom %d by x_f %.3f (priming %.3f + admitted %.3f)"
+                  % (name, e, K, p1[0], p1[1], p1[2], K, p2[0], p2[1], p2[2]))
+            print("%-28s modelled wave-instructions per document: now %.2f | primed %.2f (%+.0f %%) | + x_f extremes %.2f (%+.0f %%)" % (
+                "", insts(e), insts(p1[0], p1[1]), 100 * (insts(p1[0], p1[1]) / insts(e) - 1), insts(p2[0], p2[1]), 100 * (insts(p2[0], p2[1]) / insts(e) - 1)))
+    elif args.mode == "pack":
         print("chains per document: 51 lanes of one group %.3f | of another %.3f | 13 lanes of the other %.3f | 51 + 13 packed %.3f" % (
             chains_eager(k1, y, starts)[0], chains_eager(k2, y, starts)[0], chains_eager(k2[:, :13], y, starts)[0],
             chains_eager(np.concatenate([k1, k2[:, :13]], axis=1), y, starts)[0]))
