@@ -20,7 +20,7 @@ namespace frdev {
 
 enum Measure : int { M_NDCG = 0, M_AP = 1, M_RR = 2 };
 
-// Error bound E >= |R - sum_j x_j v_j| of a trainer's resident sums (DESIGN.md section 4a), u = 2^-53, T from column
+// Error bound E >= |R - sum_j x_j v_j| of a trainer's resident sums (DESIGN.md section 4.2), u = 2^-53, T from column
 // maxima.  One place for the constants: the trainer (host.hpp), compute_eps2 (device_dataset.inc) and the CPU test
 // that replays the device's update arithmetic against extended precision (tests/test_error_bound.py, through
 // fr_debug_resident_bound) all use these.

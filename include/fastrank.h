@@ -199,7 +199,7 @@ const void *fr_profile_json(void);
 /* hipDeviceSynchronize; 0 on success. */
 int fr_synchronize(void);
 /* The constants of the resident-sum error bound the trainer and the bound-and-verify kernels use (DESIGN.md
- * section 4a), so that a CPU test can replay the device's update arithmetic against extended precision with the
+ * section 4.2), so that a CPU test can replay the device's update arithmetic against extended precision with the
  * product's own numbers.  which = 0: bound after an exact refresh (a = feature count, b = T);
  * 1: bound after one incremental update (a = previous bound, b = norm, c = T);
  * 2: the term a candidate key's error bound gains from the resident form (a = bound, b = norm, c = T).

@@ -50,3 +50,39 @@ def test_pmc_constants_carry_the_hash_of_their_sources(tmp_path, monkeypatch):
     (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps({"30k": {"bench_timed_bytes_per_group": 1.0}}))
     tj, meta = bench.load_pmc("30k", usable=True)
     assert meta["stale"] is True and tj["bench_timed_bytes_per_group"] == 1.0
+
+
+def test_thread_ranks_exchange_like_process_ranks():
+    """bench.py --gpus N from a plain shell runs its ranks as host threads (ThreadComm): barrier, reductions in rank order,
+    the gather of restart records and the shared block counter must behave like their torch.distributed counterparts."""
+    import threading
+
+    world = 3
+    hub = bench.ThreadHub(world)
+    out = [None] * world
+
+    def body(rank):
+        c = bench.ThreadComm(hub, rank)
+        s = c.allreduce([float(rank + 1), 0.1 * (rank + 1)], "sum")
+        m = c.allreduce([float(rank)], "max")
+        rows = c.allgather_rows([float(rank), float(rank * rank)])
+        mine = [{"restart_id": r, "score": float(r), "weights": [float(r)]} for r in range(rank, 7, world)]
+        allr = c.gather_restarts(mine, 7)
+        blocks = list(c.steal_blocks(10, 3))
+        c.barrier()
+        blocks2 = list(c.steal_blocks(4, 4))  # (a second job gets its own counter)
+        out[rank] = (s, m, rows, [r["restart_id"] for r in allr], blocks, blocks2)
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(o is not None for o in out)
+    for s, m, rows, ids, _, _ in out:
+        assert s == [6.0, (0.1 + 0.2) + 0.30000000000000004] and m == [2.0]  # added in rank order: the same bits on every rank
+        assert rows == [[0.0, 0.0], [1.0, 1.0], [2.0, 4.0]] and ids == list(range(7))
+    assert sorted(b for o in out for b in o[4]) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert sorted(b for o in out for b in o[5]) == [(0, 4)]
+    single = bench.SingleComm()
+    assert single.allreduce([1.0], "sum") == [1.0] and list(single.steal_blocks(5, 2)) == [(0, 2), (2, 4), (4, 5)]

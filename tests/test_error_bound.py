@@ -1,4 +1,4 @@
-"""The constant behind the bound-and-verify line search (DESIGN.md section 4a), checked on the CPU: the
+"""The constant behind the bound-and-verify line search (DESIGN.md section 4.2), checked on the CPU: the
 reference's sequentially rounded f64 sum s (oracle) and any other summation of the same products lie within
 gamma_D * T of the real-number sum, T = sum_j |x_j * w_j|, and the per-candidate constant the host uses
 (column maxima instead of the document's own |x_j|) dominates it.  A statistical check of the analysis, not
@@ -51,7 +51,7 @@ def test_bound_is_tight_enough_to_be_useful():
     assert np.median(gaps) > 1e6 * eps
 
 
-# ---- the resident-sum recurrence (DESIGN.md section 4a; VERDICT r01 weak #2) ---------------------------------
+# ---- the resident-sum recurrence (DESIGN.md section 4.2; VERDICT r01 weak #2) ---------------------------------
 def _bound(which, a, b, c=0.0):
     from fastrank_amd import clib
 

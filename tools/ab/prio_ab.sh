@@ -1,5 +1,5 @@
 #!/bin/bash
-# (record of a withdrawn experiment: the FR_LS_PRIO switch it drives was removed again after this A/B)
+# (record of a withdrawn experiment: the FR_LS_PRIO switch it drives was removed again after this A/B, DESIGN.md section 4.9 (round 3: git history))
 # stream priorities for the tick's tail: FR_LS_FIFO x FR_LS_PRIO on one box
 cd "$GRAFT_REPO_ROOT"
 m() { FR_LS_FIFO=$1 FR_LS_PRIO=$2 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "

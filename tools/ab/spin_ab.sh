@@ -1,5 +1,5 @@
 #!/bin/bash
-# (record of a withdrawn experiment: the FR_SPIN_WAIT_US switch it drives was removed again after this A/B)
+# (record of a withdrawn experiment: the FR_SPIN_WAIT_US switch it drives was removed again after this A/B, DESIGN.md section 4.9 (round 3: git history))
 cd "$GRAFT_REPO_ROOT"
 m() { env $1 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys

@@ -1,6 +1,6 @@
 // Issue rate of a few VALU instructions on gfx950, one wave per SIMD and eight: every thread runs a long unrolled stream of
 // INDEPENDENT instances (16 accumulators) of one instruction; cycles per wave-instruction per SIMD = waves_on_simd * clocks
-// / instructions.  tools/ab/ubench.sh runs it; the numbers are quoted in DESIGN.md section 4c.
+// / instructions.  tools/ab/ubench.sh runs it; the numbers are quoted in DESIGN.md section 4.5.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
