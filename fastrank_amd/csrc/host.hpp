@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -903,8 +904,21 @@ class RestartQueue {
     const uint32_t end_;
 };
 
+// accumulates the wall time of a scope in microseconds (FR_HOST_TIMING=1 prints the trainer's totals when it is destroyed)
+struct HostTimer {
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 class CATrainer {
   public:
+    ~CATrainer() {
+        if (getenv("FR_HOST_TIMING") && host_calls_)
+            fprintf(stderr, "[host timing] %llu set-ticks: stage + submit %.1f us (of which staging the groups %.1f), wait + collect %.1f us, replay %.1f us per set and tick\n",
+                    (unsigned long long)host_calls_, host_us_[0] / host_calls_, host_us_[3] / host_calls_, host_us_[1] / host_calls_, host_us_[2] / host_calls_);
+    }
     // slot / device: which device-side copy of the view this trainer runs on (DatasetView::device_ptr(slot, device);
     // slot 0 = the view's first device form).  train_model gives every device its own trainer.
     // This form trains the fixed range [rbegin, rend), all of it live from the start.
@@ -1054,7 +1068,11 @@ class CATrainer {
             bool stop = false;
             auto submit = [&](int h) {
                 size_t unused = 0;
-                if (stop || steps[h] >= budget || !build_groups(h, groups_h_[h], &unused)) return;
+                HostTimer ht_(host_us_[0]);
+                {
+                    HostTimer hb_(host_us_[3]);
+                    if (stop || steps[h] >= budget || !build_groups(h, groups_h_[h], &unused)) return;
+                }
                 stats_.line_searches++;
                 dev.set_sums_only(false);
                 std::string _err;
@@ -1108,13 +1126,20 @@ class CATrainer {
                         unsigned long long p0 = 0, r0 = 0, p1 = 0, r1 = 0;
                         dev.verify_counters(&p0, &r0);
                         inflight[h] = false;
-                        collect(h);
+                        {
+                            HostTimer ht_(host_us_[1]);
+                            collect(h);
+                        }
                         dev.verify_counters(&p1, &r1);
                         stats_.verify_pairs += p1 - p0;
                         stats_.verify_redone += r1 - r0;
                         check_flags(dev);
                         stats_.groups += groups_h_[h].size();
-                        apply_results(h, means_h_[h]);
+                        {
+                            HostTimer ht_(host_us_[2]);
+                            apply_results(h, means_h_[h]);
+                        }
+                        host_calls_++;
                         steps[h]++;
                         if (newly_done_ > 0) done_wait_++;
                         if (refill_wanted()) stop = true;
@@ -1431,6 +1456,8 @@ class CATrainer {
     std::vector<uint64_t> child_;           // child seeds of all num_restarts restarts, drawn in order (:211-213)
     std::vector<RestartResult> finished_;   // restarts whose place was handed to a later one
     size_t newly_done_ = 0, refill_min_ = 1, done_wait_ = 0;
+    double host_us_[4] = {0.0, 0.0, 0.0, 0.0};  // stage + submit / wait + collect / replay (FR_HOST_TIMING)
+    unsigned long long host_calls_ = 0;
     std::vector<frdev::LineGroup> groups_, groups_h_[frdev::DeviceDataset::LINESEARCH_CONTEXTS];
     std::vector<double> means_h_[frdev::DeviceDataset::LINESEARCH_CONTEXTS];
     int parts_ = 1;  // sets of restarts run() keeps in flight

@@ -23,13 +23,16 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 gmax = max(int(r["Grid_Size_X"]) for r in rows)
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 iso = [r for r in rows if int(r["Grid_Size_X"]) == gmax]
-rest = [r for r in rows if int(r["Grid_Size_X"]) != gmax]
-warm, timed = rest[:9], rest[9:]
+first_iso, last_iso = rows.index(iso[0]), rows.index(iso[-1])
+rest = rows[:first_iso]                 # warm-up, timed, then the instrumented pipelined steps (bench.py's legs in order)
+e2e = rows[last_iso + 1:]               # the train-to-convergence leg
+warm, timed, instr = rest[:9], rest[9:69], rest[69:]
 print("rocprofv3 --kernel-trace of `python bench.py --steps 20 --warmup 3`: linesearch_verify_kernel launches by kind")
-for name, sel in (("warm-up (3 ticks x 3 sets)", warm), ("timed (20 ticks x 3 sets, overlapping)", timed), ("isolated lock-step (32 groups)", iso)):
+for name, sel in (("warm-up (3 ticks x 3 sets)", warm), ("timed (20 ticks x 3 sets, overlapping)", timed), ("instrumented pipelined steps after them", instr),
+                  ("isolated lock-step (32 groups)", iso), ("train-to-convergence leg (408 ticks x 3 sets, fewer groups as restarts converge)", e2e)):
     if sel:
         d = [dur(r) for r in sel]
-        print("%-42s n=%-3d avg %.4f ms  min %.4f  max %.4f" % (name, len(d), sum(d) / len(d), min(d), max(d)))
+        print("%-42s n=%-4d avg %.4f ms  min %.4f  max %.4f" % (name, len(d), sum(d) / len(d), min(d), max(d)))
 if timed:
     t0, t1 = int(timed[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in timed)
     print("timed launches span %.3f ms -> %.4f ms per tick" % ((t1 - t0) / 1e6, (t1 - t0) / 1e6 / (len(timed) / 3.0)))
