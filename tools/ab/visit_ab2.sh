@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two kernels_verify.inc variants by the kernel's own duration over 80 lock-step launches (rocprofv3 kernel trace) and by
-# its VALU instruction count: B = the tree's variant, A = tools/ab/kernels_verify_A.inc
+# its VALU instruction count: B = the tree's variant, A = tools/ab/kernels_verify_A.inc (git-ignored: put the other variant there, e.g. `git show HEAD~1:fastrank_amd/csrc/kernels_verify.inc`)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r04d
 one() {
   rm -rf gpurun_out/r04d/kt_$1
