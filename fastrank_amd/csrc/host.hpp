@@ -1192,6 +1192,27 @@ class CATrainer {
     bool in_part(size_t k, int part) const {
         if (part < 0) return true;
         const size_t R = rs_.size(), P = (size_t)parts_;
+        // FR_LS_SPLIT=a,b,c (a measurement aid): the sets' shares of the restarts, e.g. 14,11,7, instead of equal thirds --
+        // unequal sets fall out of step with each other
+        static const std::vector<size_t> split = [] {
+            std::vector<size_t> v;
+            if (const char* e = getenv("FR_LS_SPLIT"))
+                for (const char* p = e; *p;) {
+                    char* end = nullptr;
+                    const long x = strtol(p, &end, 10);
+                    if (end == p) break;
+                    v.push_back((size_t)std::max<long>(x, 1));
+                    p = *end ? end + 1 : end;
+                }
+            return v;
+        }();
+        if (split.size() == P) {
+            size_t tot = 0, lo = 0;
+            for (size_t x : split) tot += x;
+            for (size_t i = 0; i < (size_t)part; i++) lo += split[i];
+            const size_t b = R * lo / tot, e = (size_t)part + 1 == P ? R : R * (lo + split[(size_t)part]) / tot;
+            return k >= b && k < e;
+        }
         return k >= R * (size_t)part / P && k < R * ((size_t)part + 1) / P;
     }
 
