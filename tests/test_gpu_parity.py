@@ -1133,6 +1133,38 @@ def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, 
     assert ref["restarts"] == st["restarts"]
 
 
+@pytest.mark.parametrize("switch", ["FR_LS_GRAPH=1", "FR_TICK_DIRECT=0", "FR_LS_GRAPH=1,FR_TICK_DIRECT=0"])
+def test_tick_plumbing_switches_keep_the_trajectory(small, switch, monkeypatch):
+    """How a tick's queue entries reach the device (one by one, or captured once and replayed as one executable graph) and how
+    its results come back (written into page-locked memory by the last kernel, or by a copy of their own) must not change
+    anything: every restart on the oracle's trajectory, the same counters as the default, ragged call chunking included
+    (a graph is re-captured whenever the number of live groups changes)."""
+    X, y, qid, g, c = small
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 23, True, 7, 5
+    ref = native.train_model_shard(g, req, 0, 7)
+    for kv in switch.split(","):
+        k, v = kv.split("=")
+        monkeypatch.setenv(k, v)
+    run = native.CoordinateAscentRun(g, req)
+    chunks = [3, 1, 7, 64]
+    k = 0
+    while not run.finished:
+        run.step(chunks[k % len(chunks)])
+        k += 1
+    st = run.state()
+    run.close()
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=4)
+    assert err == 0
+    for r in st["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), switch
+    assert st["restarts"] == ref["restarts"]
+    for key in ("useful_evals", "raw_evals", "ticks", "groups", "verify_pairs"):
+        assert st["stats"][key] == ref["stats"][key], (switch, key)
+
+
 def test_two_interleaved_trainers_on_one_dataset(small):
     """Only one trainer can own a dataset's resident sums; the one that loses them must keep producing
     the oracle's trajectory (it forms its sums from the tiles again)."""
