@@ -5,11 +5,12 @@ Python/NumPy/CPU implementation to fall back to -- if the library is missing or 
 visible, compute calls raise.
 
 The objects are compiled in parallel (fullverify.hip once per slice of the size classes of the full-ranking kernel:
--DFV_PART=k) and cached under fastrank_amd/build/ by source time stamps, so editing one kernel family rebuilds one or
-a few objects.
+-DFV_PART=k) and cached under fastrank_amd/build/ by a digest of their sources, so editing one kernel family rebuilds one
+or a few objects.
 """
 import concurrent.futures
 import fcntl
+import hashlib
 import os
 import re
 import shutil
@@ -56,36 +57,45 @@ def _extra_flags():
     return os.environ.get("FR_BUILD_FLAGS", "").split()  # kernel-tuning experiments (-DFV_... ...)
 
 
-def _stale(obj, src, deps) -> bool:
+def _digest(src, extra, deps) -> str:
+    """What an object (or, over all units, the library) was built from: the contents of its source and of everything it
+    includes, the compiler flags.  Staleness is judged by this, not by time stamps -- a tree that was copied (to the GPU
+    box) or checked out keeps whatever mtimes the copy gave it."""
+    h = hashlib.sha1()
+    h.update(" ".join(FLAGS + _extra_flags() + list(extra)).encode())
+    for name in [src] + list(deps):
+        path = os.path.join(CSRC, name)
+        h.update(b"\0" + name.encode() + b"\0")
+        if os.path.exists(path):
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def _lib_digest() -> str:
+    h = hashlib.sha1()
+    for obj, src, extra, deps in units():
+        h.update((obj + ":" + _digest(src, extra, deps) + "\n").encode())
+    return h.hexdigest()
+
+
+def _stale(obj, src, extra, deps) -> bool:
     path = os.path.join(OBJ_DIR, obj)
-    if not os.path.exists(path):
-        return True
-    built = os.path.getmtime(path)
     flag_file = path + ".flags"
-    if not os.path.exists(flag_file) or open(flag_file).read() != " ".join(_extra_flags()):
-        return True
-    files = [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in deps]
-    return any(os.path.exists(p) and os.path.getmtime(p) > built for p in files)
+    return not (os.path.exists(path) and os.path.exists(flag_file) and open(flag_file).read() == _digest(src, extra, deps))
 
 
 def needs_build() -> bool:
-    """The library is current if it is newer than every source (the objects are a cache: a tree that travelled without
-    fastrank_amd/build/, e.g. to the GPU box, is not rebuilt)."""
-    if not os.path.exists(LIB_PATH):
-        return True
-    built = os.path.getmtime(LIB_PATH)
+    """The library is current if it was built from exactly these sources and flags (libfastrank_amd.so.flags holds their
+    digest; the objects under fastrank_amd/build/ are only a cache: a tree that travelled without them, e.g. to the GPU
+    box, is not rebuilt)."""
     flag_file = LIB_PATH + ".flags"
-    if (open(flag_file).read() if os.path.exists(flag_file) else "") != " ".join(_extra_flags()):
-        return True
-    for _, src, _, deps in units():
-        files = [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in deps]
-        if any(os.path.exists(p) and os.path.getmtime(p) > built for p in files):
-            return True
-    return False
+    return not (os.path.exists(LIB_PATH) and os.path.exists(flag_file) and open(flag_file).read() == _lib_digest())
 
 
-def _compile(hipcc, obj, src, extra, verbose):
+def _compile(hipcc, obj, src, extra, deps, verbose):
     path = os.path.join(OBJ_DIR, obj)
+    digest = _digest(src, extra, deps)  # (of what is compiled now: taken before the compiler reads the files)
     tmp = "%s.%d.tmp" % (path, os.getpid())
     cmd = [hipcc] + FLAGS + _extra_flags() + extra + ["-c", os.path.join(CSRC, src), "-o", tmp]
     if verbose:
@@ -95,7 +105,7 @@ def _compile(hipcc, obj, src, extra, verbose):
         raise RuntimeError("hipcc failed on %s %s:\n%s" % (src, " ".join(extra), proc.stdout))
     os.replace(tmp, path)
     with open(path + ".flags", "w") as fh:
-        fh.write(" ".join(_extra_flags()))
+        fh.write(digest)
     return obj
 
 
@@ -117,11 +127,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = hipcc_path()
-    todo = [(o, s, e) for o, s, e, d in units() if force or _stale(o, s, d)]
+    lib_digest = _lib_digest()
+    todo = [(o, s, e, d) for o, s, e, d in units() if force or _stale(o, s, e, d)]
     jobs = max(1, min(len(todo), int(os.environ.get("FR_BUILD_JOBS", str(os.cpu_count() or 4)))))
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
-            futs = [pool.submit(_compile, hipcc, o, s, e, verbose) for o, s, e in todo]
+            futs = [pool.submit(_compile, hipcc, o, s, e, d, verbose) for o, s, e, d in todo]
             for f in futs:
                 f.result()
     objs = [os.path.join(OBJ_DIR, o) for o, _, _, _ in units()]
@@ -134,7 +145,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
         raise RuntimeError("link failed:\n" + proc.stdout)
     os.replace(tmp, LIB_PATH)
     with open(LIB_PATH + ".flags", "w") as fh:
-        fh.write(" ".join(_extra_flags()))
+        fh.write(lib_digest)
     return LIB_PATH
 
 
