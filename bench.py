@@ -750,6 +750,9 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
                       "first_call_with_replication": runs[0], "second_call": runs[1], "model_sha1": sha,
                       "same_model_as_e2e_leg": (sha == e2e["model_sha1"]) if e2e is not None else None}
             native.release_replicas(dataset)
+        except Exception as exc:  # (a side leg: its failure must not cost the bench line -- it is reported in it)
+            inproc = {"what": "dataset.train_model(request) with FR_DEVICES={}".format(inproc_list),
+                      "error": "{}: {}".format(type(exc).__name__, str(exc)[:500])}
         finally:
             if old_env is None:
                 del os.environ["FR_DEVICES"]
