@@ -27,6 +27,7 @@
 #include "device.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "fullverify.hpp"
 
