@@ -1133,6 +1133,35 @@ def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, 
     assert ref["restarts"] == st["restarts"]
 
 
+@pytest.mark.parametrize("nlabels", [40, 200, 300])
+def test_many_gain_classes_train_on_the_oracle_trajectory(nlabels):
+    """The NDCG@k verify kernel reads its DCG terms from a copy of the gain-class table in LDS whose size follows the number
+    of distinct gains (standard collections have 2-5; graded or continuous relevance has many): 40 and 200 classes go
+    through it, more than 256 classes send the line search to the exact kernel -- the trajectory is the oracle's each time."""
+    rng = np.random.default_rng(100 + nlabels)
+    X, y, qid = synth_dataset(31, 5000, 24, 50, max_len=400)
+    levels = np.round(np.linspace(0.0, 4.0, nlabels), 6)
+    y = rng.choice(levels, size=len(y)).astype(np.float64)
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+    try:
+        for measure in ("ndcg@10", "ndcg@5", "ndcg@20"):
+            req = fr.TrainRequest.coordinate_ascent()
+            req.measure = measure
+            p = req.params
+            p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 5, True, 4, 4
+            got = native.train_model_shard(g, req, 0, 4)
+            exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=4)
+            assert err == 0
+            for r in got["restarts"]:
+                assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), (nlabels, measure)
+            assert got["stats"]["useful_evals"] == int(exp_e.sum())
+            if nlabels <= 256:
+                assert got["stats"]["verify_pairs"] > 0  # (the bound-and-verify kernel took the line searches)
+    finally:
+        o.set_mean_segment(0)
+
+
 @pytest.mark.parametrize("switch", ["FR_LS_GRAPH=1", "FR_TICK_DIRECT=0", "FR_LS_GRAPH=1,FR_TICK_DIRECT=0"])
 def test_tick_plumbing_switches_keep_the_trajectory(small, switch, monkeypatch):
     """How a tick's queue entries reach the device (one by one, or captured once and replayed as one executable graph) and how
