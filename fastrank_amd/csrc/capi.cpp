@@ -151,6 +151,8 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("verify_pairs", Value::uint(s.verify_pairs));
     o.set("verify_redone", Value::uint(s.verify_redone));
     o.set("exact_ticks", Value::uint(s.exact_ticks));
+    o.set("exact_groups", Value::uint(s.exact_groups));
+    o.set("verify_redo_entries", Value::uint(s.verify_redo_entries));
     o.set("line_searches", Value::uint(s.line_searches));
     o.set("audit_values", Value::uint(s.audit_values));
     o.set("audit_mismatches", Value::uint(s.audit_mismatches));
@@ -491,6 +493,7 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
         total.restarts += stats[i].restarts, total.refills += stats[i].refills;
         total.verify_pairs += stats[i].verify_pairs, total.verify_redone += stats[i].verify_redone;
         total.line_searches += stats[i].line_searches, total.exact_ticks += stats[i].exact_ticks;
+        total.exact_groups += stats[i].exact_groups, total.verify_redo_entries += stats[i].verify_redo_entries;
         total.audit_values += stats[i].audit_values, total.audit_mismatches += stats[i].audit_mismatches;
     }
     std::sort(hist.begin(), hist.end(), [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });

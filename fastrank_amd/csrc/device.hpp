@@ -165,8 +165,13 @@ class DeviceDataset {
     const std::vector<double>& column_absmax() const;  // per-column max |x|
     // running totals: (run, group) pairs given to the bound-and-verify kernel / recomputed exactly
     void verify_counters(unsigned long long* pairs, unsigned long long* redone) const;
-    // line searches that skipped bound-and-verify because a recent one had > 25 % of its pairs redone
+    // line searches evaluated by the exact kernels alone (NDCG@k: every group of the line search was routed there; the other
+    // measures: a recent line search had > 25 % of its pairs redone)
     unsigned long long exact_fallbacks() const;
+    // NDCG@k: group line searches routed to the exact kernel (a restart whose last verified line search left > 25 % of its
+    // pairs undecided goes there for 4, 8, 16 line searches; the other groups of the tick stay on the verify kernel), and
+    // the (query, group, 16-candidate slice) entries the verify kernel listed for recomputation
+    void routing_counters(unsigned long long* exact_groups, unsigned long long* redo_entries) const;
     // FR_VERIFY_AUDIT=1: values re-derived by the exact kernel after a bound-and-verify line search / how many differed
     void audit_counters(unsigned long long* values, unsigned long long* mismatches) const;
     // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----

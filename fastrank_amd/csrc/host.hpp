@@ -797,7 +797,9 @@ struct TrainStats {
     uint64_t verify_pairs = 0, verify_redone = 0;
     uint64_t line_searches = 0;  // batched line searches submitted (one per tick in lock step, one per set and tick when pipelined)
     uint64_t audit_values = 0, audit_mismatches = 0;  // FR_VERIFY_AUDIT=1 (see include/fastrank.h)
-    uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone after a tick with > 25 % redone pairs
+    uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone (every group routed there / after a tick with > 25 % redone pairs)
+    uint64_t exact_groups = 0;         // NDCG@k: group line searches routed to the exact kernel (of `groups`)
+    uint64_t verify_redo_entries = 0;  // NDCG@k: (query, group, 16-candidate slice) entries the exact kernel recomputed
     uint32_t devices = 1;      // devices train_model spread the restarts over (ticks = the longest device's)
     uint32_t refills = 0;      // times converged restarts handed their places to the next ids of the restart queue
     int device = -1;           // ordinal this trainer ran on (per-device entries of train_model's statistics)
@@ -807,11 +809,17 @@ struct TrainStats {
 struct ExactTickCount {
     frdev::DeviceDataset& dev;
     TrainStats& st;
-    unsigned long long base, av0 = 0, am0 = 0;
-    ExactTickCount(frdev::DeviceDataset& d, TrainStats& s) : dev(d), st(s), base(d.exact_fallbacks()) { d.audit_counters(&av0, &am0); }
+    unsigned long long base, av0 = 0, am0 = 0, eg0 = 0, re0 = 0;
+    ExactTickCount(frdev::DeviceDataset& d, TrainStats& s) : dev(d), st(s), base(d.exact_fallbacks()) {
+        d.audit_counters(&av0, &am0);
+        d.routing_counters(&eg0, &re0);
+    }
     ~ExactTickCount() {
-        unsigned long long av1 = 0, am1 = 0;
+        unsigned long long av1 = 0, am1 = 0, eg1 = 0, re1 = 0;
         dev.audit_counters(&av1, &am1);
+        dev.routing_counters(&eg1, &re1);
+        st.exact_groups += eg1 - eg0;
+        st.verify_redo_entries += re1 - re0;
         st.exact_ticks += dev.exact_fallbacks() - base;
         st.audit_values += av1 - av0;
         st.audit_mismatches += am1 - am0;
@@ -1192,27 +1200,6 @@ class CATrainer {
     bool in_part(size_t k, int part) const {
         if (part < 0) return true;
         const size_t R = rs_.size(), P = (size_t)parts_;
-        // FR_LS_SPLIT=a,b,c (a measurement aid): the sets' shares of the restarts, e.g. 14,11,7, instead of equal thirds --
-        // unequal sets fall out of step with each other
-        static const std::vector<size_t> split = [] {
-            std::vector<size_t> v;
-            if (const char* e = getenv("FR_LS_SPLIT"))
-                for (const char* p = e; *p;) {
-                    char* end = nullptr;
-                    const long x = strtol(p, &end, 10);
-                    if (end == p) break;
-                    v.push_back((size_t)std::max<long>(x, 1));
-                    p = *end ? end + 1 : end;
-                }
-            return v;
-        }();
-        if (split.size() == P) {
-            size_t tot = 0, lo = 0;
-            for (size_t x : split) tot += x;
-            for (size_t i = 0; i < (size_t)part; i++) lo += split[i];
-            const size_t b = R * lo / tot, e = (size_t)part + 1 == P ? R : R * (lo + split[(size_t)part]) / tot;
-            return k >= b && k < e;
-        }
         return k >= R * (size_t)part / P && k < R * ((size_t)part + 1) / P;
     }
 

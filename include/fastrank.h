@@ -146,12 +146,15 @@ void fr_ca_free(void *trainer);
 const CResult *fr_select_model(const void *restarts_json, int output_ensemble);
 /* JSON stats of the most recent train_model / fr_train_model_shard call in this process:
  * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts","verify_pairs","verify_redone",
- *  "exact_ticks","line_searches","audit_values","audit_mismatches","devices","refills"} and, after a call that ran
+ *  "exact_ticks","exact_groups","verify_redo_entries","line_searches","audit_values","audit_mismatches","devices",
+ *  "refills"} and, after a call that ran
  * on several devices, "per_device": the same object for every entry of the device list (its "device", "restarts",
  * "ticks", "seconds", "refills": times converged restarts handed their places to ids from the shared restart queue)
  * (path: "fused_linesearch" | "fused_fullrank" | "generic_sort"; verify_*: (query, group) pairs evaluated by the
- * bound-and-verify kernels and how many of them were recomputed by the exact kernels; exact_ticks of line_searches
- * batched line searches went to the exact kernels alone; audit_*: with FR_VERIFY_AUDIT=1 every published NDCG@k
+ * bound-and-verify kernels and how many of them were recomputed by the exact kernels -- NDCG@k recomputes only the
+ * 16-candidate slices of a pair that hold an undecided candidate: verify_redo_entries counts those; exact_ticks of
+ * line_searches batched line searches went to the exact kernels alone, exact_groups of groups single restarts' line
+ * searches were routed there while the rest of their tick stayed on the verify kernel; audit_*: with FR_VERIFY_AUDIT=1 every published NDCG@k
  * value is recomputed by the exact kernel and compared bit for bit -- values compared / values that differed). */
 const void *fr_last_train_stats(void);
 

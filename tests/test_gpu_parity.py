@@ -920,6 +920,67 @@ def test_verify_kernel_near_ties_below_the_error_bound():
         assert np.array_equal(pq[:, ci], exp), ci
 
 
+def test_tie_heavy_restarts_are_routed_to_the_exact_kernel_one_by_one(monkeypatch):
+    """Per-group routing (DeviceDataset::linesearch_ndcg_submit): documents duplicated with DIFFERENT labels tie exactly under
+    every weight vector, so -- with the duplicate groups switched off -- the verify kernel cannot decide most pairs of any
+    restart.  A restart whose verified line search left more than a quarter of its pairs undecided sends its next 4 / 8 /
+    16 line searches straight to the exact kernel; the trainer's other sets keep using the verify kernel.  The trajectory
+    is the oracle's either way, some group line searches were routed, and not every line search went to the exact kernel
+    wholesale (round 4 sent the next 16 line searches of EVERY group there)."""
+    monkeypatch.setenv("FR_NO_DUP_GROUPS", "1")
+    rng = np.random.default_rng(131)
+    X, y, qid = synth_dataset(131, 8000, 10, 80, max_len=200)
+    X = np.abs(X)
+    for i in np.nonzero(rng.random(len(y)) < 0.5)[0]:
+        if i > 0 and qid[i - 1] == qid[i]:
+            X[i] = X[i - 1]            # same features, its own label
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 5, True, 6, 5
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=3)
+    assert err == 0
+    shard, st = _train_stats(g, req)
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    assert st["useful_evals"] == int(exp_e.sum())
+    print("routing:", {k: st[k] for k in ("groups", "exact_groups", "exact_ticks", "line_searches", "verify_pairs", "verify_redone")})
+    if _verify_path_on(resident_needed=True):
+        assert 0 < st["exact_groups"] < st["groups"], st
+        assert st["verify_pairs"] > 0 and st["verify_redone"] * 4 > st["verify_pairs"], st  # (what triggers the routing)
+
+
+def test_redo_unit_is_a_slice_of_sixteen_candidates():
+    """Pairs of documents that differ ONLY in feature 0 and carry different labels tie exactly for the candidate w_0 = 0
+    (the `dir = 0` candidate, src/coordinate_ascent.rs:152-155 -- candidate 0 of a line search on feature 0) and for no
+    other: the verify kernel lists the (query, group) pair with a mask that names the first 16-candidate slice only, and
+    the exact kernel recomputes one slice per listed pair instead of four.  Values: the oracle's, bit for bit."""
+    rng = np.random.default_rng(137)
+    nq, per, d = 300, 16, 6
+    X = rng.uniform(1.0, 2.0, (nq * per, d)).astype(np.float32)
+    y = rng.integers(0, 4, nq * per).astype(np.float64)
+    qid = np.repeat(np.arange(1, nq + 1), per)
+    X[1::2, 1:] = X[0::2, 1:]          # pairs equal in every feature but 0
+    y[0::2], y[1::2] = 3.0, 1.0        # ... of different gains, and the best of the query
+    X[0::2, 1] += 4.0
+    X[1::2, 1] += 4.0
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations, p.init_random = 3, True, 3, 25, False
+    exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=3)
+    assert err == 0
+    shard, st = _train_stats(g, req)
+    for r in shard["restarts"]:
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
+    print("slices:", {k: st[k] for k in ("verify_pairs", "verify_redone", "verify_redo_entries", "exact_groups")})
+    if _verify_path_on(resident_needed=True):
+        assert st["verify_redone"] > 0, st
+        assert st["verify_redo_entries"] < 2 * st["verify_redone"], st  # (four per pair without the masks: 51 candidates = 4 slices)
+
+
 def _with_same_label_duplicates(seed, n, d, nq, frac=0.1):
     """Duplicated documents that carry their source's label: exact score ties for every weight vector, none of
     which the reference's tie-break has to decide between gain classes (the continuous columns keep
@@ -1073,11 +1134,10 @@ def test_resident_sums_never_refreshed_on_adversarial_columns(measure, monkeypat
         assert st["audit_values"] > 0 and st["audit_mismatches"] == 0, st
 
 
-@pytest.mark.parametrize("env", [{}, {"FR_RESIDENT_REFRESH": "2"}, {"FR_LS_RESIDENT": "0"}, {"FR_VERIFY_GW": "4"},
-                                 {"FR_LS_EXACT": "1"}])
+@pytest.mark.parametrize("env", [{}, {"FR_RESIDENT_REFRESH": "2"}, {"FR_LS_RESIDENT": "0"}, {"FR_LS_EXACT": "1"}])
 def test_trainer_variants_share_one_trajectory(small, env, monkeypatch):
     """Resident base sums (updated incrementally on acceptance, refreshed exactly every N updates), sums
-    from the tiles, several groups per wave, exact kernel only: all of them train to the oracle's result."""
+    from the tiles (two groups per wave), exact kernel only: all of them train to the oracle's result."""
     X, y, qid, g, c = small
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -1162,21 +1222,15 @@ def test_many_gain_classes_train_on_the_oracle_trajectory(nlabels):
         o.set_mean_segment(0)
 
 
-@pytest.mark.parametrize("switch", ["FR_LS_GRAPH=1", "FR_TICK_DIRECT=0", "FR_LS_GRAPH=1,FR_TICK_DIRECT=0"])
-def test_tick_plumbing_switches_keep_the_trajectory(small, switch, monkeypatch):
-    """How a tick's queue entries reach the device (one by one, or captured once and replayed as one executable graph) and how
-    its results come back (written into page-locked memory by the last kernel, or by a copy of their own) must not change
-    anything: every restart on the oracle's trajectory, the same counters as the default, ragged call chunking included
-    (a graph is re-captured whenever the number of live groups changes)."""
+def test_ragged_call_chunking_keeps_the_trajectory(small):
+    """However the caller chunks its fr_ca_step calls (3, 1, 7, 64 ticks ...), every restart stays on the oracle's
+    trajectory and the counters are those of one uninterrupted run."""
     X, y, qid, g, c = small
     req = fr.TrainRequest.coordinate_ascent()
     req.measure = "ndcg@10"
     p = req.params
     p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 23, True, 7, 5
     ref = native.train_model_shard(g, req, 0, 7)
-    for kv in switch.split(","):
-        k, v = kv.split("=")
-        monkeypatch.setenv(k, v)
     run = native.CoordinateAscentRun(g, req)
     chunks = [3, 1, 7, 64]
     k = 0
@@ -1188,10 +1242,10 @@ def test_tick_plumbing_switches_keep_the_trajectory(small, switch, monkeypatch):
     exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=4)
     assert err == 0
     for r in st["restarts"]:
-        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), switch
+        assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist()
     assert st["restarts"] == ref["restarts"]
     for key in ("useful_evals", "raw_evals", "ticks", "groups", "verify_pairs"):
-        assert st["stats"][key] == ref["stats"][key], (switch, key)
+        assert st["stats"][key] == ref["stats"][key], key
 
 
 def test_two_interleaved_trainers_on_one_dataset(small):
