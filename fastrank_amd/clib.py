@@ -94,6 +94,7 @@ def _load():
         "fr_debug_fullrank_class": (C.c_uint32, [C.c_uint32]),
         "fr_debug_restart_queue": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]),
         "fr_dataset_release_replicas": (sz, [vp]),
+        "fr_debug_peer_copy": (vp, [C.c_int, C.c_int, sz]),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(L, name)

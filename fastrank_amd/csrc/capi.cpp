@@ -982,6 +982,26 @@ const void* fr_debug_device_plan(const void* devices_csv, int device_count, uint
     });
 }
 
+// One timed device-to-device copy of `bytes` bytes src -> dst, made like the dataset copies of train_model's fan-out:
+// {"src","dst","bytes","can_access","enabled","ms","gbps"}.
+const void* fr_debug_peer_copy(int src_device, int dst_device, size_t bytes) {
+    return json_call([&]() {
+        int can = 0, en = 0;
+        double ms = 0.0;
+        std::string err;
+        if (!frdev::peer_copy_probe(src_device, dst_device, bytes, &can, &en, &ms, &err)) fr::fail_str(err);
+        Value o = Value::object();
+        o.set("src", Value::uint((uint64_t)src_device));
+        o.set("dst", Value::uint((uint64_t)dst_device));
+        o.set("bytes", Value::uint((uint64_t)bytes));
+        o.set("can_access", Value::boolean(can != 0));
+        o.set("enabled", Value::boolean(en != 0));
+        o.set("ms", Value::number(ms));
+        o.set("gbps", Value::number(ms > 0.0 ? (double)bytes / (ms * 1e-3) / 1e9 : 0.0));
+        return frjson::dump(o);
+    });
+}
+
 int fr_set_device(int ordinal) {
     std::string err;
     if (!frdev::set_device(ordinal, &err)) return 1;

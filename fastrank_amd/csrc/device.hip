@@ -15,6 +15,7 @@
 //   kernels_linesearch.inc  linesearch_ndcg_kernel: the exact fused NDCG@k line search
 //   kernels_verify.inc      linesearch_verify_kernel: bound-and-verify NDCG@k line search (the hot path; the exact
 //                           kernel recomputes the pairs it cannot verify)
+//   kernels_order.inc       xslot_kernel / rslot_kernel: the verify kernel's visiting-order tables (by x_f, by the resident sums)
 //   kernels_fullrank.inc    linesearch_scores_kernel + rank_metric_kernel: AP / RR / depth-less NDCG
 //   kernels_rr.inc          rr_verify_kernel / rr_exact_kernel: reciprocal rank by bound-and-verify
 //   fullverify.hpp          interface to fullverify.hip (own objects, compiled per slice of the size classes):
@@ -55,6 +56,7 @@ namespace frdev {
 #include "kernels_metric.inc"
 #include "kernels_linesearch.inc"
 #include "kernels_chain.inc"
+#include "kernels_order.inc"
 #include "kernels_verify.inc"
 #include "kernels_fullrank.inc"
 #include "kernels_rr.inc"

@@ -230,6 +230,8 @@ void profile_enable(bool on);
 void profile_reset();
 std::vector<KernelStat> profile_stats();
 bool device_synchronize(std::string* err);
+// one timed device-to-device copy src -> dst as replicate() makes them (device_plumbing.inc)
+bool peer_copy_probe(int src, int dst, size_t bytes, int* can_access, int* enabled, double* ms, std::string* err);
 size_t device_free_bytes();
 // page-locked host memory (nullptr when none is left: the caller falls back to ordinary memory); for staging uploads that
 // a helper thread prepares -- a copy from ordinary memory ran at under 1 GB/s on some of the boxes this was measured on

@@ -252,6 +252,11 @@ def restart_queue_replay(num_restarts: int, n_workers: int, capacity: int, lengt
     return _json_reply(_load().fr_debug_restart_queue(int(num_restarts), int(n_workers), int(capacity), arr.ctypes.data, len(arr)))
 
 
+def peer_copy(src_device: int, dst_device: int, nbytes: int = 256 << 20) -> Dict:
+    """One timed device-to-device copy made like train_model's dataset copies: {"can_access", "enabled", "ms", "gbps", ...}."""
+    return _json_reply(_load().fr_debug_peer_copy(int(src_device), int(dst_device), int(nbytes)))
+
+
 def release_replicas(dataset: CDataset) -> int:
     """Frees the copies of the dataset train_model made on other devices / in other contexts; returns how many."""
     return int(_load().fr_dataset_release_replicas(dataset.pointer))

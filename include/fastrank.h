@@ -228,6 +228,11 @@ const void *fr_debug_device_plan(const void *devices_csv, int device_count, uint
  * `capacity`. */
 const void *fr_debug_restart_queue(uint32_t num_restarts, uint32_t n_workers, uint32_t capacity, const uint32_t *lengths,
                                    uint32_t n_lengths);
+/* One timed device-to-device copy of `bytes` bytes from device `src_device` to device `dst_device`, made the way
+ * train_model's fan-out copies a dataset to another GPU (peer access enabled where the link allows, hipMemcpyPeerAsync):
+ * JSON {"src","dst","bytes","can_access","enabled","ms","gbps"}.  A first-contact check of the peer path on a multi-GPU
+ * node (bench.py --gpus N reports it per device pair); src == dst measures a copy inside one device. */
+const void *fr_debug_peer_copy(int src_device, int dst_device, size_t bytes);
 /* Frees the device-to-device copies train_model made of this dataset on other devices / in other contexts (they are kept
  * with the dataset so that the next request reuses them; a node shared with other jobs may want the HBM back).  The
  * dataset's first device form stays.  Returns the number of copies released. */
