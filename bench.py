@@ -407,6 +407,26 @@ def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
     }
 
 
+def rccl_is_mandatory(backend, world, visible_gpus, pinned_device):
+    """--backend nccl on a node where every rank has a GPU of its own: an RCCL failure is an error, not a reason to fall back
+    to gloo (the fallback exists for smoke tests that put several ranks on ONE GPU, which RCCL refuses by design)."""
+    return backend == "nccl" and world > 1 and pinned_device is None and visible_gpus >= world
+
+
+def peer_copy_report(native, devices, nbytes=256 << 20):
+    """One timed device-to-device copy (made like the dataset copies of train_model's fan-out) from the first device to every
+    other device of the job: {can_access, enabled, gbps} per pair -- first-contact evidence for hipMemcpyPeerAsync over xGMI."""
+    out, src = [], devices[0]
+    for dst in list(dict.fromkeys(devices[1:])) or [src]:
+        try:
+            r = native.peer_copy(src, dst, nbytes)
+            out.append({"src": src, "dst": dst, "can_access": r["can_access"], "enabled": r["enabled"], "gbps": r["gbps"], "ms": r["ms"],
+                        "same_device": src == dst})
+        except Exception as exc:
+            out.append({"src": src, "dst": dst, "error": "{}: {}".format(type(exc).__name__, str(exc)[:200])})
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -483,6 +503,8 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend, note = args.backend, None
+        must_be_rccl = rccl_is_mandatory(backend, int(os.environ.get("WORLD_SIZE", "1") or 1), torch.cuda.device_count(),
+                                         os.environ.get("FR_BENCH_DEVICE"))
         if backend == "nccl":
             try:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_ordinal), timeout=datetime.timedelta(seconds=300))
@@ -490,6 +512,10 @@ def main():
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
             except Exception as exc:  # RCCL could not start on this node: the job has no data-path collective, gloo carries the rest
+                if must_be_rccl:  # one distinct GPU per rank and RCCL was asked for: a gloo run must not pass for an RCCL run
+                    raise SystemExit("bench.py --backend nccl: RCCL failed to start with {} ranks on {} visible GPUs ({}: {}); not falling "
+                                     "back to gloo -- rerun with --backend gloo to measure without RCCL".format(
+                                         os.environ.get("WORLD_SIZE"), torch.cuda.device_count(), type(exc).__name__, str(exc)[:300]))
                 note = "nccl (RCCL) failed to start: {}: {}; using gloo".format(type(exc).__name__, str(exc)[:200])
                 print("[bench.py] " + note, file=sys.stderr, flush=True)
                 try:
@@ -723,7 +749,7 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
         rows = comm.allgather_rows([float(ticks), busy_s, float(e_stats["useful_evals"]), float(e_stats["raw_evals"]),
                                     float(len(mine)), float(e_stats["verify_pairs"]), float(e_stats["verify_redone"]),
                                     float(e_stats["exact_ticks"]), e2e_s, float(e_stats["line_searches"]),
-                                    float(e_stats["exact_groups"]), float(e_stats["groups"])])
+                                    float(e_stats["exact_groups"]), float(e_stats["groups"]), float(dev_ordinal), float(rank)])
         wall = max(r[8] for r in rows)
         busy = [r[1] for r in rows]
         best = max(allr, key=lambda r: r["score"])
@@ -743,6 +769,10 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
             "redo_fraction": (sum(r[6] for r in rows) / sum(r[5] for r in rows)) if sum(r[5] for r in rows) else None,
             "exact_line_search_share": (sum(r[7] for r in rows) / max(1.0, sum(r[9] for r in rows))),
             "exact_group_share": (sum(r[10] for r in rows) / max(1.0, sum(r[11] for r in rows))),
+            # who took part, from the all-gather itself: one row per rank, its rank id and the device ordinal it drove
+            "ranks_seen": len(rows),
+            "rank_ids_seen": sorted(int(r[13]) for r in rows),
+            "devices_seen": [int(r[12]) for r in rows],
             "best_score": best["score"],
             "model_sha1": hashlib.sha1(json.dumps(model.to_dict(), sort_keys=True).encode()).hexdigest(),
         }
@@ -787,6 +817,10 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
                 del os.environ["FR_DEVICES"]
             else:
                 os.environ["FR_DEVICES"] = old_env
+    peer = None
+    if rank == 0 and world > 1:
+        devs = list(thread_devices) if threads_mode else ([dev_ordinal] * world if os.environ.get("FR_BENCH_DEVICE") is not None else list(range(world)))
+        peer = peer_copy_report(native, devs)
     if threads_mode:
         comm.barrier()
 
@@ -972,6 +1006,7 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
             "timed_region_instrumented": profile_timed,
             "e2e": e2e,
             "inprocess": inproc,
+            "peer_copy": peer,
             "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "best_score_so_far": best_so_far},
         }
         if world == 1 and not args.no_cpu_baseline:

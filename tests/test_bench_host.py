@@ -86,3 +86,33 @@ def test_thread_ranks_exchange_like_process_ranks():
     assert sorted(b for o in out for b in o[5]) == [(0, 4)]
     single = bench.SingleComm()
     assert single.allreduce([1.0], "sum") == [1.0] and list(single.steal_blocks(5, 2)) == [(0, 2), (2, 4), (4, 5)]
+
+
+def test_rccl_failure_is_an_error_only_when_every_rank_has_its_own_gpu():
+    """`--backend nccl` on a node with one GPU per rank must not turn into a gloo run silently; several ranks
+    pinned to ONE GPU (what the one-GPU box can exercise) legitimately fall back."""
+    assert bench.rccl_is_mandatory("nccl", 8, 8, None) is True
+    assert bench.rccl_is_mandatory("nccl", 2, 8, None) is True
+    assert bench.rccl_is_mandatory("nccl", 2, 1, None) is False     # two ranks, one GPU visible
+    assert bench.rccl_is_mandatory("nccl", 2, 8, "0") is False      # FR_BENCH_DEVICE pins every rank to one ordinal
+    assert bench.rccl_is_mandatory("gloo", 8, 8, None) is False
+    assert bench.rccl_is_mandatory("nccl", 1, 8, None) is False
+
+
+def test_peer_copy_report_covers_every_other_device_and_survives_errors():
+    class FakeNative:
+        def __init__(self):
+            self.calls = []
+
+        def peer_copy(self, src, dst, nbytes):
+            self.calls.append((src, dst))
+            if dst == 3:
+                raise RuntimeError("no such device")
+            return {"can_access": True, "enabled": True, "gbps": 48.0, "ms": 5.6}
+
+    fake = FakeNative()
+    rep = bench.peer_copy_report(fake, [0, 1, 2, 3])
+    assert fake.calls == [(0, 1), (0, 2), (0, 3)]
+    assert [r["dst"] for r in rep] == [1, 2, 3] and rep[0]["gbps"] == 48.0 and "error" in rep[2]
+    rep = bench.peer_copy_report(FakeNative(), [0, 0])  # two ranks on one GPU: one same-device copy
+    assert len(rep) == 1 and rep[0]["same_device"] is True
