@@ -383,7 +383,11 @@ static uint32_t min_restarts_per_device() {
 // The device list of one train_model call over `units` independent pieces of work (restarts, trees), with the view's
 // device-side copies made: an empty / one-entry plan means "train on one device" (slot 0 = the view's first device
 // form; slot 1 = a copy on the one device an explicit list names when the first form lives elsewhere).
-static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& view, uint32_t units, uint32_t min_units_per_device = 1) {
+// slots_max (coordinate ascent): the restarts one trainer keeps live; the list is cut to the entries that get restarts when
+// every trainer takes its share from the one queue at the start (5 restarts over 4 devices are 2 + 2 + 1, the
+// fourth entry would have made a dataset copy and an empty trainer).
+static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& view, uint32_t units, uint32_t min_units_per_device = 1,
+                                      uint32_t slots_max = 0) {
     std::vector<int> devs = fr_train_devices();
     const bool explicit_list = std::getenv("FR_DEVICES") != nullptr;
     if (!explicit_list) {
@@ -394,6 +398,10 @@ static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& vi
         devs.resize(std::min(devs.size(), by_floor));
     }
     if (devs.size() > units) devs.resize(std::max<uint32_t>(units, 1));
+    if (slots_max > 0 && devs.size() > 1) {
+        const uint32_t cap = std::max<uint32_t>(1, std::min<uint32_t>(slots_max, (uint32_t)((units + devs.size() - 1) / devs.size())));
+        devs.resize(std::min<size_t>(devs.size(), (units + cap - 1) / cap));
+    }
     auto single = [&](const std::vector<int>& d, bool pin) {
         if (d.empty()) return plan_devices(d, units, -1);
         if (pin) {
@@ -452,7 +460,7 @@ static DevicePlan devices_for_request(const std::shared_ptr<fr::DatasetView>& vi
 fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const ParsedRequest& rq) {
     const uint32_t R = rq.ca.num_restarts;
     auto t0 = std::chrono::steady_clock::now();
-    const DevicePlan pl = devices_for_request(view, R, min_restarts_per_device());
+    const DevicePlan pl = devices_for_request(view, R, min_restarts_per_device(), restart_slots_max());
     if (pl.devs.empty() || (pl.devs.size() == 1 && pl.slot[0] == 0)) return train_ca(view, rq, 0, R, nullptr);
     fr::Evaluator ev = fr::make_evaluator(*view, rq.measure, rq.has_qrel ? &rq.qrel : nullptr);
     if (view->host_csr().nq == 0) fr::fail_str("assertion failed: !data.queries().is_empty()");
@@ -515,10 +523,14 @@ fr::Model train_rf(const std::shared_ptr<fr::DatasetView>& view, const ParsedReq
     // the trees of a forest are independent given their seeds (random_forest.rs:301-331 grows them with rayon): spread
     // over FR_DEVICES like a coordinate-ascent request's restarts, block i of the trees on entry i of the list
     std::vector<fr::RFTrainer::DevicePart> parts;
-    if (rq.rf.num_trees > 0 && rq.rf.quiet) {  // (a forest that prints its progress table grows on one device: no copies made)
-        const DevicePlan pl = devices_for_request(view, rq.rf.num_trees);
-        if (pl.devs.size() > 1)
-            for (size_t i = 0; i < pl.devs.size(); i++) parts.push_back(fr::RFTrainer::DevicePart{pl.slot[i], pl.devs[i], pl.begin[i], pl.end[i]});
+    if (rq.rf.num_trees > 0) {
+        // (a forest that prints its progress table grows on one device -- one unit of work, so no copies are made -- but an
+        // explicit FR_DEVICES / fr_set_device choice of that device is still honoured)
+        const DevicePlan pl = devices_for_request(view, rq.rf.quiet ? rq.rf.num_trees : 1);
+        // several entries, or ONE entry that names a device other than the one the dataset was built on (slot 1: its copy there)
+        if (pl.devs.size() > 1 || (pl.devs.size() == 1 && pl.slot[0] != 0))
+            for (size_t i = 0; i < pl.devs.size(); i++)
+                parts.push_back(fr::RFTrainer::DevicePart{pl.slot[i], pl.devs[i], rq.rf.quiet ? pl.begin[i] : 0u, rq.rf.quiet ? pl.end[i] : rq.rf.num_trees});
     }
     fr::Model m = trainer.learn(std::move(parts));
     fr::TrainStats st;

@@ -235,7 +235,9 @@ const void *fr_debug_restart_queue(uint32_t num_restarts, uint32_t n_workers, ui
 const void *fr_debug_peer_copy(int src_device, int dst_device, size_t bytes);
 /* Frees the device-to-device copies train_model made of this dataset on other devices / in other contexts (they are kept
  * with the dataset so that the next request reuses them; a node shared with other jobs may want the HBM back).  The
- * dataset's first device form stays.  Returns the number of copies released. */
+ * dataset's first device form stays.  Returns the number of copies released.  Views sampled from the dataset
+ * (dataset_query_sampling, train_test_split ...) that were trained on several devices hold copies of their own -- over
+ * the same copied matrix -- and are released the same way, each through its own handle. */
 size_t fr_dataset_release_replicas(const CDataset *dataset);
 
 #ifdef __cplusplus

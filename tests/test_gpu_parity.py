@@ -1223,6 +1223,32 @@ def test_many_gain_classes_train_on_the_oracle_trajectory(nlabels):
         o.set_mean_segment(0)
 
 
+def test_many_gain_classes_on_a_wide_matrix_without_resident_sums(monkeypatch):
+    """ADVICE r04: sums formed from the tiles (FR_LS_RESIDENT=0) keep two groups' weights in LDS next to the gain-class table;
+    with ~200 classes and ~1800 columns that no longer fits a workgroup's 64 KB.  The launch must not fail: such a line
+    search goes to the exact kernel (a narrower matrix with the same classes still takes the verify kernel), and the
+    values are the oracle's."""
+    monkeypatch.setenv("FR_LS_RESIDENT", "0")
+    rng = np.random.default_rng(77)
+    nlabels = 200
+    for d, expect_verify in ((1800, False), (64, True)):
+        X, y, qid = synth_dataset(33, 1500, d, 20, max_len=200)
+        y = rng.choice(np.round(np.linspace(0.0, 4.0, nlabels), 6), size=len(y)).astype(np.float64)
+        g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+        req = fr.TrainRequest.coordinate_ascent()
+        req.measure = "ndcg@10"
+        p = req.params
+        p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 9, True, 2, 3
+        run = native.CoordinateAscentRun(g, req)
+        run.step(6)
+        st = run.state()
+        run.close()
+        for r in st["restarts"]:
+            assert c.evaluate_mean("ndcg@10", np.asarray(r["weights"])) == r["score"], d
+        if _verify_path_on():
+            assert (st["stats"]["verify_pairs"] > 0) == expect_verify, (d, st["stats"])
+
+
 def test_ragged_call_chunking_keeps_the_trajectory(small):
     """However the caller chunks its fr_ca_step calls (3, 1, 7, 64 ticks ...), every restart stays on the oracle's
     trajectory and the counters are those of one uninterrupted run."""
