@@ -1225,12 +1225,12 @@ def test_many_gain_classes_train_on_the_oracle_trajectory(nlabels):
 
 def test_many_gain_classes_on_a_wide_matrix_without_resident_sums(monkeypatch):
     """ADVICE r04: sums formed from the tiles (FR_LS_RESIDENT=0) keep two groups' weights in LDS next to the gain-class table;
-    with ~200 classes and ~1800 columns that no longer fits a workgroup's 64 KB.  The launch must not fail: such a line
+    with ~240 classes and ~1800 columns that no longer fits a workgroup's 64 KB.  The launch must not fail: such a line
     search goes to the exact kernel (a narrower matrix with the same classes still takes the verify kernel), and the
     values are the oracle's."""
     monkeypatch.setenv("FR_LS_RESIDENT", "0")
     rng = np.random.default_rng(77)
-    nlabels = 200
+    nlabels = 240
     for d, expect_verify in ((1800, False), (64, True)):
         X, y, qid = synth_dataset(33, 1500, d, 20, max_len=200)
         y = rng.choice(np.round(np.linspace(0.0, 4.0, nlabels), 6), size=len(y)).astype(np.float64)
