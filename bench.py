@@ -50,7 +50,7 @@ FP64_VALU_PEAK_TADDS = 39.3    # 78.6 TFLOP/s FP64 vector (FMA = 2 flop) -> 39.3
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
 # sources whose SHA-1 the PMC figures of profiles/hbm_traffic.json are tied to (tools/pmc_bench.sh records them)
-PMC_SOURCES = ("kernels_verify.inc", "kernels_linesearch.inc", "device_dataset.inc", "host.hpp")
+PMC_SOURCES = ("kernels_verify.inc", "kernels_fillnet.inc", "kernels_chain.inc", "kernels_order.inc", "kernels_linesearch.inc", "device_dataset.inc", "host.hpp")
 DATA_KINDS = ("mslr", "ties", "tiesmix", "hard", "hardties")
 
 

@@ -49,7 +49,7 @@ cp "$OUT"/kt_tree/*kernel_stats.csv "$OUT/${TAG}_tree_kernel_stats.csv" 2>/dev/n
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_full" -o p -- python tools/train_e2e.py --measure ndcg --shape 30k --restarts 32 --max-ticks 136 > "$OUT/kt_full.log" 2>&1
 cp "$OUT"/kt_full/*kernel_stats.csv "$OUT/${TAG}_fullrank_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt_full/*/*kernel_stats.csv "$OUT/${TAG}_fullrank_kernel_stats.csv"
 # side measurements on tie-heavy and on hard data: bench line + a whole run each
-for kind in ties tiesmix hard; do
+for kind in ties tiesmix hard hardties; do
   python bench.py --steps 20 --warmup 3 --data $kind --no-cpu-baseline 2> "$OUT/bench_$kind.err" | tail -1 > "$OUT/${TAG}_bench_$kind.json"
 done
 # the N>1 path on one GPU (gloo, both ranks on device 0): strong scaling of a 32-restart job, static and work stealing
@@ -65,7 +65,7 @@ python tools/viewbench.py 2>&1 | tail -1 > "$OUT/${TAG}_views_30k.json"
 python bench.py --measure trees --steps 20 --warmup 3 2> "$OUT/bench_trees.err" | tail -1 > "$OUT/${TAG}_bench_trees.json"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --inprocess-devices 0,0 2> "$OUT/bench_inproc.err" | tail -1 > "$OUT/${TAG}_bench_inprocess_2ctx_1gpu.json"
 { for m in ndcg@50 ndcg@100; do python tools/train_e2e.py --measure $m --shape 30k --restarts 32 --max-ticks 136 2>&1 | tail -1; done; } > "$OUT/${TAG}_train_ndcg_cut_30k.json"
-FR_UPLOAD_TIMING=1 python tools/train_e2e.py --shape 30k --restarts 32 --max-ticks 3 2>&1 | grep "upload\]" > "$OUT/${TAG}_upload_stages.txt"
+FR_UPLOAD_TIMING=1 python tools/train_e2e.py --shape 30k --restarts 32 --max-ticks 3 2>&1 | grep "upload" > "$OUT/${TAG}_upload_stages.txt"
 python tools/train_e2e.py 2>&1 | tail -1 > "$OUT/${TAG}_train_e2e_10k.json"
 python tools/train_e2e.py --measure mrr --shape 30k --restarts 32 --max-ticks 272 2>&1 | tail -1 > "$OUT/${TAG}_train_mrr_30k.json"
 { python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; FR_LS_EXACT=1 python tools/train_e2e.py --shape 30k --restarts 32 2>&1 | tail -1; } > "$OUT/${TAG}_train_e2e_30k.json"
