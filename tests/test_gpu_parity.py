@@ -920,6 +920,42 @@ def test_verify_kernel_near_ties_below_the_error_bound():
         assert np.array_equal(pq[:, ci], exp), ci
 
 
+def test_duplicate_pairs_tied_with_a_third_document_go_to_the_exact_kernel():
+    """The verify kernel keeps a tied pair of ONE duplicate group (bit-identical rows: the reference's gain tie-break orders
+    them, and so do the class bits of their keys) only when nothing else is tied with it.  Here a third document equals the
+    pair in every feature but one, so the `dir = 0` candidate of that feature (w_f = 0, src/coordinate_ascent.rs:152-155) ties
+    all three exactly while their gains differ: such clusters must be recomputed, never decided from the keys.  Trajectory
+    and evaluation counts are the oracle's; duplicate groups are in use and some pairs were redone."""
+    rng = np.random.default_rng(151)
+    X, y, qid = synth_dataset(151, 9000, 8, 90, max_len=200)
+    X = np.abs(X)
+    n = len(y)
+    for i in range(2, n):
+        if qid[i - 2] != qid[i]:
+            continue
+        u = rng.random()
+        if u < 0.12:
+            X[i - 1] = X[i - 2]                    # a duplicate pair with its own labels ...
+            X[i] = X[i - 2]
+            X[i, rng.integers(0, 8)] += 1.0        # ... and a third document that differs from it in one feature only
+            y[i - 2], y[i - 1], y[i] = rng.permutation([0.0, 1.0, 2.0])
+    g, c = fr.CDataset.from_numpy(X, y, qid), o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations, p.init_random = 47, True, 4, 5, False
+    for init_random in (False, True):
+        p.init_random = init_random
+        exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
+        assert err == 0
+        shard, st = _train_stats(g, req)
+        for r in shard["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), init_random
+        assert st["useful_evals"] == int(exp_e.sum())
+        if _verify_path_on(resident_needed=True):
+            assert st["verify_pairs"] > 0 and st["verify_redone"] > 0, st
+
+
 def test_tie_heavy_restarts_are_routed_to_the_exact_kernel_one_by_one(monkeypatch):
     """Per-group routing (DeviceDataset::linesearch_ndcg_submit): documents duplicated with DIFFERENT labels tie exactly under
     every weight vector, so -- with the duplicate groups switched off -- the verify kernel cannot decide most pairs of any
