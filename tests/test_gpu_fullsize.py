@@ -151,6 +151,35 @@ def test_verify_path_equals_exact_kernel_at_full_size(big, monkeypatch):
     assert st_v["stats"]["useful_evals"] == st_e["stats"]["useful_evals"]
 
 
+@pytest.mark.parametrize("kind", ["mslr", "tiesmix"])
+def test_every_resident_verify_variant_runs_at_the_30k_shape(kind, monkeypatch):
+    """Round 5: one variant of linesearch_verify_kernel (K = 10, K + 2 keys) faulted at the 30K shape only -- an inline-asm
+    output overlapped the address register of the scalar load behind it, which shows when that load waits to issue, i.e.
+    under load -- while every small-size parity test of it passed.  So every resident variant (depth 5 / 10 / 20 x list
+    length K+1..K+3, without and with duplicate groups = tiesmix) takes a few ticks of real training on the whole matrix
+    here, and every value it publishes is recomputed by the exact kernel (FR_VERIFY_AUDIT: bit for bit, 0 mismatches)."""
+    n, d, q, seed = bench.SHAPES["30k"]
+    if kind == "mslr":
+        g = _shape("30k")[4]
+    else:
+        X, y, qid = bench.gen_mslr_shaped(seed, n, d, q, kind)
+        g = fr.CDataset.from_numpy(X, y, qid)
+    monkeypatch.setenv("FR_VERIFY_AUDIT", "1")
+    for measure in ("ndcg@5", "ndcg@10", "ndcg@20"):
+        for xs in ("1", "2", "3"):
+            monkeypatch.setenv("FR_VERIFY_XS", xs)
+            req = fr.TrainRequest.coordinate_ascent()
+            req.measure = measure
+            req.params.seed, req.params.quiet, req.params.num_restarts = 11, True, 6
+            run = native.CoordinateAscentRun(g, req)
+            run.step(3)
+            st = run.state()["stats"]
+            run.close()
+            if not os.environ.get("FR_LS_EXACT"):
+                assert st["verify_pairs"] > 0 and st["audit_values"] > 0, (kind, measure, xs, st)
+            assert st["audit_mismatches"] == 0, (kind, measure, xs, st)
+
+
 # ------------------------------------------------- BASELINE.json configs[4]: 500 trees x 30K shape
 
 def _forest(rng, X, ntrees, max_depth, p_leaf=0.05):
