@@ -44,6 +44,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
