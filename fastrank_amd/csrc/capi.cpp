@@ -1017,6 +1017,7 @@ const void* fr_debug_peer_copy(int src_device, int dst_device, size_t bytes) {
 int fr_set_device(int ordinal) {
     std::string err;
     if (!frdev::set_device(ordinal, &err)) return 1;
+    frdev::warm_device(ordinal);
     g_pinned_device = ordinal;  // train_model then stays on this device unless FR_DEVICES says otherwise
     return 0;
 }

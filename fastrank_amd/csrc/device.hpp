@@ -226,6 +226,7 @@ class DeviceDataset {
 // process-wide helpers -------------------------------------------------------------------------
 int device_count(std::string* err);
 bool set_device(int ordinal, std::string* err);
+void warm_device(int ordinal);  // pays the runtime's first-stream cost on that device once per process
 void profile_enable(bool on);
 void profile_reset();
 std::vector<KernelStat> profile_stats();

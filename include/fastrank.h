@@ -107,7 +107,8 @@ const void *predict_to_trecrun(const CModel *model, const CDataset *dataset, con
 
 /* Number of visible HIP devices (0 when none / no driver). */
 int fr_device_count(void);
-/* Select the device used by datasets created afterwards on this thread. 0 on success. */
+/* Select the device used by datasets created afterwards on this thread. 0 on success.  The first call for a device also
+ * pays the runtime's first-stream cost there (~80 ms once per process), so that the first dataset built on it does not. */
 int fr_set_device(int ordinal);
 /* Library/ABI version string (static storage; do NOT free). */
 const char *fr_version(void);
