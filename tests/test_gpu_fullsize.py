@@ -156,7 +156,7 @@ def test_every_resident_verify_variant_runs_at_the_30k_shape(kind, monkeypatch):
     """Round 5: one variant of linesearch_verify_kernel (K = 10, K + 2 keys) faulted at the 30K shape only -- an inline-asm
     output overlapped the address register of the scalar load behind it, which shows when that load waits to issue, i.e.
     under load -- while every small-size parity test of it passed.  So every resident variant (depth 5 / 10 / 20 x list
-    length K+1..K+3, without and with duplicate groups = tiesmix) takes a few ticks of real training on the whole matrix
+    length K+1..K+4, without and with duplicate groups = tiesmix) takes a few ticks of real training on the whole matrix
     here, and every value it publishes is recomputed by the exact kernel (FR_VERIFY_AUDIT: bit for bit, 0 mismatches)."""
     n, d, q, seed = bench.SHAPES["30k"]
     if kind == "mslr":
@@ -166,7 +166,7 @@ def test_every_resident_verify_variant_runs_at_the_30k_shape(kind, monkeypatch):
         g = fr.CDataset.from_numpy(X, y, qid)
     monkeypatch.setenv("FR_VERIFY_AUDIT", "1")
     for measure in ("ndcg@5", "ndcg@10", "ndcg@20"):
-        for xs in ("1", "2", "3"):
+        for xs in ("1", "2", "3", "4"):
             monkeypatch.setenv("FR_VERIFY_XS", xs)
             req = fr.TrainRequest.coordinate_ascent()
             req.measure = measure

@@ -1044,7 +1044,7 @@ def test_verify_kernel_accepts_ties_inside_one_gain_class(monkeypatch):
     exp_s, exp_w, exp_e, err = c.ca_learn("ndcg@10", p.to_dict(), threads=2)
     assert err == 0
     fracs = {}
-    for xs in ("1", "2", "3", ""):
+    for xs in ("1", "2", "3", "4", ""):
         if xs:
             monkeypatch.setenv("FR_VERIFY_XS", xs)
         else:
@@ -1056,7 +1056,7 @@ def test_verify_kernel_accepts_ties_inside_one_gain_class(monkeypatch):
         fracs[xs] = (st["verify_redone"] / max(1, st["verify_pairs"]), st["exact_ticks"], st["line_searches"])
     print("redo fraction / exact-only line searches / line searches by FR_VERIFY_XS:", fracs)
     if _verify_path_on(resident_needed=True):
-        assert fracs["1"][0] > fracs["2"][0] > fracs["3"][0] > 0.0, fracs
+        assert fracs["1"][0] > fracs["2"][0] > fracs["3"][0] >= fracs["4"][0], fracs
         assert fracs["3"][0] < 0.2, fracs
         assert fracs[""][0] < fracs["1"][0] and fracs[""][1] <= fracs["1"][1], fracs  # adaptive: raised after the first line searches
 
