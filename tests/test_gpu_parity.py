@@ -1192,6 +1192,33 @@ def test_trainer_variants_share_one_trajectory(small, env, monkeypatch):
     assert shard["stats"]["ticks"] > 48, "several passes over the 24 features"
 
 
+@pytest.mark.parametrize("measure", ["ndcg@10", "mrr"])
+def test_dataset_without_the_column_major_copy_trains_from_the_tiles(measure, monkeypatch):
+    """The resident line searches read their feature from the column-major copy of the tiles (as large as the matrix again).
+    A dataset made without it (FR_XCOL=0; the same happens when HBM has no room) gets no resident sums: the trainer forms
+    them from the tiles and lands on the oracle's result all the same."""
+    X, y, qid = synth_dataset(19, 5000, 24, 50, max_len=600)
+    monkeypatch.setenv("FR_XCOL", "0")
+    g = fr.CDataset.from_numpy(X, y, qid)
+    bare = native.device_info(g)["hbm_bytes_owned"]  # (the device dataset is made on first use: while the switch is set)
+    monkeypatch.delenv("FR_XCOL")
+    full = fr.CDataset.from_numpy(X, y, qid)
+    assert bare < native.device_info(full)["hbm_bytes_owned"] - X.size * 4 // 2
+    c = o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = measure
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 23, True, 3, 4
+    exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=3)
+    assert err == 0
+    for ds in (g, full):
+        shard = native.train_model_shard(ds, req, 0, 3)
+        for r in shard["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]]
+            assert r["weights"] == exp_w[r["restart_id"]].tolist()
+        assert shard["stats"]["useful_evals"] == int(exp_e.sum())
+
+
 @pytest.mark.parametrize("parts,measure", [("0", "ndcg@10"), ("2", "ndcg@10"), ("3", "ndcg@10"), ("4", "ndcg@10"),
                                            ("0", "mrr"), ("3", "mrr"), ("4", "mrr")])
 def test_pipelined_stepping_keeps_every_restart_on_the_oracle_trajectory(small, parts, measure, monkeypatch):
