@@ -36,6 +36,14 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
 #define LSHLOR(i) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));
 #define MADU24(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
 #define MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define CMPF32(i) { uint64_t m_; asm volatile("v_cmp_ge_f32 %0, %1, %2" : "=s"(m_) : "v"(a[i]), "v"(b)); acc ^= m_; }
+#define CMPU32(i) { uint64_t m_; asm volatile("v_cmp_gt_u32 %0, %1, %2" : "=s"(m_) : "v"(a[i]), "v"(b)); acc ^= m_; }
+// the compare alone: results to vcc, nothing reads them until the end of the block of 16
+#define CMPF64V(i) asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(d[i]), "v"(bd) : "vcc");
+#define CMPF32V(i) asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+// compare + the conditional move that consumes it (what an admission test followed by a select costs)
+#define CMPSEL64(i) asm volatile("v_cmp_gt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(d[i]), "v"(bd), "v"(b) : "vcc");
+#define CMPSEL32(i) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
         if constexpr (OP == 0) { REP16(U32MIN) REP16(U32MAX) }
         if constexpr (OP == 1) { REP16(F64MIN) REP16(F64MIN) }
         if constexpr (OP == 2) { REP16(F64FMA) REP16(F64FMA) }
@@ -51,6 +59,12 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
         if constexpr (OP == 12) { REP16(MULLO) REP16(MULLO) }
         if constexpr (OP == 13) { REP16(MIN3) REP16(MIN3) }
         if constexpr (OP == 14) { REP16(ADDF64) REP16(ADDF64) }
+        if constexpr (OP == 15) { REP16(CMPF32) REP16(CMPF32) }
+        if constexpr (OP == 16) { REP16(CMPU32) REP16(CMPU32) }
+        if constexpr (OP == 17) { REP16(CMPF64V) REP16(CMPF64V) }
+        if constexpr (OP == 18) { REP16(CMPF32V) REP16(CMPF32V) }
+        if constexpr (OP == 19) { REP16(CMPSEL64) REP16(CMPSEL64) }
+        if constexpr (OP == 20) { REP16(CMPSEL32) REP16(CMPSEL32) }
     }
     const long long t1 = clock64();
     uint32_t s = 0;
@@ -104,6 +118,12 @@ int main() {
         run<12>("v_mul_lo_u32", w);
         run<13>("v_min3_u32", w);
         run<14>("v_add_f64", w);
+        run<15>("v_cmp_ge_f32 -> sgpr, s_xor", w);
+        run<16>("v_cmp_gt_u32 -> sgpr, s_xor", w);
+        run<17>("v_cmp_gt_f64 -> vcc, unread", w);
+        run<18>("v_cmp_ge_f32 -> vcc, unread", w);
+        run<19>("v_cmp_gt_f64 + v_cndmask (2 inst)", w);
+        run<20>("v_cmp_ge_f32 + v_cndmask (2 inst)", w);
     }
     return 0;
 }
