@@ -427,6 +427,50 @@ def peer_copy_report(native, devices, nbytes=256 << 20):
     return out
 
 
+def parse_rocm_smi(txt, ordinal):
+    """(socket power in W, shader clock in MHz) of GPU[ordinal] from `rocm-smi --showpower --showclocks` text; None if absent."""
+    import re
+    watts = mhz = None
+    for line in txt.splitlines():
+        if not line.startswith("GPU[%d]" % ordinal):
+            continue
+        m = re.search(r"(?:Current Socket|Average) Graphics Package Power \(W\):\s*([0-9.]+)", line)
+        if m:
+            watts = float(m.group(1))
+        m = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", line)
+        if m:
+            mhz = int(m.group(1))
+    return None if watts is None or mhz is None else (watts, mhz)
+
+
+def power_sampler(stop, samples, ordinal):
+    """Host thread: rocm-smi in a loop while the device steps (the tool takes ~0.3 s per call).  Never raises."""
+    import subprocess
+    while not stop.is_set():
+        try:
+            txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 text=True, timeout=10).stdout
+        except Exception:
+            return
+        s = parse_rocm_smi(txt, ordinal)
+        if s is not None and not stop.is_set():
+            samples.append(s)
+
+
+def power_cap_watts(ordinal):
+    import re
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showmaxpower"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
+    except Exception:
+        return None
+    for line in txt.splitlines():
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", line)
+        if m and line.startswith("GPU[%d]" % ordinal):
+            return float(m.group(1))
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -450,6 +494,7 @@ def parse_args():
                          "API gets.  With --launcher threads it defaults to the ranks' devices")
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the power / clock leg (rocm-smi sampled while more steps run; N = 1 only)")
     ap.add_argument("--backend", default=os.environ.get("FR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch launcher: nccl = RCCL over xGMI (default; falls back to gloo if it cannot start); gloo for "
                          "single-GPU smoke tests of the N>1 path")
@@ -710,6 +755,31 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
                 iso_evals = snapshot()["raw_evals"] - i0["raw_evals"]
             finally:
                 del os.environ["FR_LS_PIPELINE"]
+    # Socket power and shader clock while the device steps (the hot kernel runs the socket at its power cap, which
+    # is why bytes and lanes not moved show up as time).  One GPU only, after everything that is timed: more pipelined steps
+    # (until four samples are in, six seconds at most) with rocm-smi sampled by a host thread.  Not part of `value`.
+    power = None
+    smi_index = int(dev_ordinal)  # rocm-smi lists the node's GPUs: a visibility list renumbers them for this process
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        ids = [t.strip() for t in os.environ.get(var, "").split(",") if t.strip()]
+        if ids:
+            smi_index = int(ids[smi_index]) if smi_index < len(ids) and ids[smi_index].isdigit() else -1
+    if world == 1 and solo and args.measure == "ndcg@10" and not args.no_power and smi_index >= 0:
+        import threading
+        samples, stop = [], threading.Event()
+        th = threading.Thread(target=power_sampler, args=(stop, samples, smi_index), daemon=True)
+        tp = time.perf_counter()
+        th.start()
+        while len(samples) < 4 and time.perf_counter() - tp < 6.0:  # (the tool's first call alone takes about a second)
+            advance(200)
+        comm.sync_device()
+        stop.set()
+        th.join(timeout=15)
+        if samples:
+            ws, cs = sorted(w for w, _ in samples), sorted(c for _, c in samples)
+            power = {"socket_w_min_median_max": [ws[0], ws[len(ws) // 2], ws[-1]], "sclk_mhz_min_median_max": [cs[0], cs[len(cs) // 2], cs[-1]],
+                     "cap_w": power_cap_watts(smi_index), "rocm_smi_index": smi_index, "samples": len(samples), "seconds": time.perf_counter() - tp,
+                     "during": "pipelined steps after everything that is timed (until four samples are in); rocm-smi --showpower --showclocks sampled by a host thread"}
     if threads_mode:
         comm.barrier()  # (the other rank threads wait here while rank 0 runs its instrumented legs)
 
@@ -986,6 +1056,7 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
             "roofline": roofline,
             "limiter": limiter,
             "pmc": pmc_meta,
+            "power": power,
             "verify": {
                 "pairs": vp, "redone": vr, "redo_fraction": (vr / vp) if vp else None,
                 "ticks": s1["ticks"] - s0["ticks"],

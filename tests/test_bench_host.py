@@ -116,3 +116,19 @@ def test_peer_copy_report_covers_every_other_device_and_survives_errors():
     assert [r["dst"] for r in rep] == [1, 2, 3] and rep[0]["gbps"] == 48.0 and "error" in rep[2]
     rep = bench.peer_copy_report(FakeNative(), [0, 0])  # two ranks on one GPU: one same-device copy
     assert len(rep) == 1 and rep[0]["same_device"] is True
+
+
+def test_power_leg_parses_rocm_smi_text_per_device():
+    """bench.py's power / clock leg reads `rocm-smi --showpower --showclocks` as text: the figures of the rank's own device,
+    nothing when the tool prints something else (the leg then leaves `power` null instead of failing the bench)."""
+    import bench
+    txt = ("GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\n"
+           "GPU[0]\t\t: sclk clock level: 1: (2211Mhz)\n"
+           "GPU[0]\t\t: socclk clock level: S: (70Mhz)\n"
+           "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1358.0\n"
+           "GPU[1]\t\t: sclk clock level: S: (94Mhz)\n"
+           "GPU[1]\t\t: Average Graphics Package Power (W): 242.0\n")
+    assert bench.parse_rocm_smi(txt, 0) == (1358.0, 2211)
+    assert bench.parse_rocm_smi(txt, 1) == (242.0, 94)
+    assert bench.parse_rocm_smi(txt, 2) is None
+    assert bench.parse_rocm_smi("rocm-smi: command not found", 0) is None
