@@ -370,41 +370,112 @@ def load_pmc(shape, usable):
     return tj, meta
 
 
-def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10"):
-    """Times oracle/ (the C restatement of the reference algorithm; kind="port") on the host
-    cores: threads over restarts only, like rayon in the reference.  Bounded sample."""
+def oracle_check(X, y, qid, measure, model_dict, device_score):
+    """After the e2e leg, outside everything timed: the selected model's weights through the ORACLE's evaluate_mean
+    (oracle/fastrank_oracle.c restating src/evaluators.rs:173-224 + src/dense_dataset.rs:67-76; the HIP path's 256-query
+    summation shape) on the whole matrix, against the score the device trained to -- bitwise.  One evaluation, ~2 s of
+    one host core.  The oracle is the checker here, never the thing measured."""
+    try:
+        from oracle import pyoracle as o
+
+        lin = model_dict.get("Linear")
+        if lin is None:
+            return {"ok": None, "note": "selected model is not Linear: {}".format(list(model_dict))}
+        t0 = time.perf_counter()
+        ds = o.Dataset(X, y, qid)
+        o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+        try:
+            got = float(ds.evaluate_mean(measure, np.asarray(lin["weights"], dtype=np.float64)))
+        finally:
+            o.set_mean_segment(0)
+        return {"ok": bool(got == device_score), "oracle": got, "device": device_score, "abs_diff": abs(got - device_score),
+                "seconds": time.perf_counter() - t0,
+                "what": "oracle evaluate_mean({}) of the selected model's weights on all {} docs == the device's best_score, bitwise".format(measure, len(y))}
+    except Exception as exc:  # (a check outside the timed region: its failure is reported in the line, not hidden)
+        return {"ok": False, "error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
+
+
+def cpu_baseline(X, y, qid, params, target_seconds, measure="ndcg@10", restarts=32):
+    """Times oracle/ (the C restatement of the reference algorithm; kind="port") on the host cores: threads over
+    restarts only, like rayon in the reference, threads = min(restarts of the config, cores).
+    Bounded sample.  `wide` is a second, shorter sample with one thread per restart on up to 64 cores (what a caller
+    with more restarts than the config's would get from the same host)."""
     from oracle import pyoracle as o
 
     cores = os.cpu_count() or 1          # the node's logical cores (SURVEY 8d: stated next to the number)
-    threads = max(1, min(cores, 64))     # threads the port actually used: one per restart, like rayon over restarts
     ds = o.Dataset(X, y, qid)
-    p = dict(params)
-    p["num_restarts"] = threads
 
-    def run(max_evals):
+    def sample(threads, seconds, nsamples):
+        p = dict(params)
+        p["num_restarts"] = threads      # one restart per thread: restart-only parallelism, every thread busy
+
+        def run(max_evals):
+            t0 = time.perf_counter()
+            _, _, evals, _ = ds.ca_learn(measure, p, threads=threads, max_evals_per_restart=max_evals)
+            return int(evals.sum()), time.perf_counter() - t0
+
+        _, t1 = run(2)
+        per_round = t1 / 2.0
+        m = int(max(2, min(200, round(seconds / nsamples / max(per_round, 1e-6)))))
+        runs = [run(m) for _ in range(nsamples)]
+        rates = sorted(nn / tt for nn, tt in runs)
+        return {"value": rates[len(rates) // 2], "threads": threads, "samples": [nn / tt for nn, tt in runs],
+                "min_median_max": [rates[0], rates[len(rates) // 2], rates[-1]],
+                "sample": "{} samples, each {} restarts x {} evaluate_mean calls of the same CA run ({} evals in {:.1f} s altogether); "
+                          "oracle/fastrank_oracle.c, per-call query regrouping hoisted".format(
+                              nsamples, threads, m, sum(nn for nn, _ in runs), sum(tt for _, tt in runs)),
+                "evals_per_s_per_core": rates[len(rates) // 2] / threads}
+
+    threads = max(1, min(cores, int(restarts)))
+    wide_threads = max(1, min(cores, 64))
+    main = sample(threads, target_seconds * (0.65 if wide_threads != threads else 1.0), 3)
+    out = {"value": main["value"], "unit": "evals/s", "cores": cores, "threads": threads, "kind": "port",
+           "samples": main["samples"], "min_median_max": main["min_median_max"], "sample": main["sample"],
+           "evals_per_s_per_core": main["evals_per_s_per_core"]}
+    if wide_threads != threads:
+        out["wide"] = sample(wide_threads, target_seconds * 0.35, 1)
+    return out
+
+
+def side_kind(args, comm, fr, native, req, kind, begin, end, headline_value):
+    """A side line inside the driver's own record: the same timed region (warm-up, then exactly --steps pipelined ticks)
+    on `kind` data (hardties = weak label signal + integer columns + duplicated rows: what real MSLR-WEB30K looks like to
+    the bound-and-verify kernel), after everything that is timed.  Not part of `value`."""
+    n, d, q, seed = SHAPES[args.shape]
+    t0 = time.perf_counter()
+    X, y, qid = gen_mslr_shaped(seed, n, d, q, kind)
+    gen_s = time.perf_counter() - t0
+    ds = fr.CDataset.from_numpy(X, y, qid)
+    run = native.CoordinateAscentRun(ds, req, begin, end)
+    try:
+        run.step(args.warmup)
+        s0 = run.state()["stats"]
+        comm.sync_device()
         t0 = time.perf_counter()
-        _, _, evals, _ = ds.ca_learn(measure, p, threads=threads, max_evals_per_restart=max_evals)
-        return int(evals.sum()), time.perf_counter() - t0
-
-    n1, t1 = run(2)
-    per_round = t1 / 2.0
-    # three samples of a third of the budget each (the spread is reported; `value` is their median)
-    m = int(max(2, min(200, round(target_seconds / 3.0 / max(per_round, 1e-6)))))
-    samples = [run(m) for _ in range(3)]
-    rates = sorted(nn / tt for nn, tt in samples)
-    n2, t2 = sum(nn for nn, _ in samples), sum(tt for _, tt in samples)
-    return {
-        "value": rates[1],
-        "unit": "evals/s",
-        "cores": cores,
-        "threads": threads,
-        "kind": "port",
-        "samples": [nn / tt for nn, tt in samples],
-        "min_median_max": [rates[0], rates[1], rates[2]],
-        "sample": "3 samples, each {} restarts x {} evaluate_mean calls of the same CA run ({} evals in {:.1f} s altogether); "
-                  "oracle/fastrank_oracle.c, per-call query regrouping hoisted".format(threads, m, n2, t2),
-        "evals_per_s_per_core": rates[1] / threads,
-    }
+        run.step(args.steps)
+        comm.sync_device()
+        el = time.perf_counter() - t0
+        s1 = run.state()["stats"]
+        psteps = max(1, min(args.steps, 10))
+        native.profile_reset()
+        native.profile_enable(True)
+        run.step(psteps)
+        comm.sync_device()
+        native.profile_enable(False)
+        prof = native.profile_stats()
+    finally:
+        run.close()
+        del ds
+    useful = s1["useful_evals"] - s0["useful_evals"]
+    vp, vr = s1["verify_pairs"] - s0["verify_pairs"], s1["verify_redone"] - s0["verify_redone"]
+    value = useful / el
+    return {"data": kind, "value": value, "unit": "evals/s", "ms_per_step": el * 1e3 / max(1, args.steps), "steps": args.steps,
+            "of_headline": (value / headline_value) if headline_value else None,
+            "redo_fraction": (vr / vp) if vp else None,
+            "exact_group_share": (s1["exact_groups"] - s0["exact_groups"]) / max(1, s1["groups"] - s0["groups"]),
+            "exact_kernel_ms_per_step": prof.get("linesearch_ndcg_kernel", {"total_ms": 0.0})["total_ms"] / psteps,
+            "kernels_ms_per_step": {k: v["total_ms"] / psteps for k, v in prof.items()},
+            "generate_s": gen_s}
 
 
 def rccl_is_mandatory(backend, world, visible_gpus, pinned_device):
@@ -494,6 +565,7 @@ def parse_args():
                          "API gets.  With --launcher threads it defaults to the ranks' devices")
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("FR_BENCH_CPU_SECONDS", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the hardties side line (headline run on one GPU only)")
     ap.add_argument("--no-power", action="store_true", help="skip the power / clock leg (rocm-smi sampled while more steps run; N = 1 only)")
     ap.add_argument("--backend", default=os.environ.get("FR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch launcher: nccl = RCCL over xGMI (default; falls back to gloo if it cannot start); gloo for "
@@ -847,6 +919,8 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
             "model_sha1": hashlib.sha1(json.dumps(model.to_dict(), sort_keys=True).encode()).hexdigest(),
         }
         e2e_top = e2e["e2e_evals_per_s"]
+        if rank == 0:
+            e2e["oracle_check"] = oracle_check(X, y, qid, args.measure, model.to_dict(), best["score"])
     else:
         e2e_top = None
 
@@ -1080,8 +1154,14 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
             "peer_copy": peer,
             "setup": {"generate_s": gen_s, "upload_and_init_s": upload_s, "best_score_so_far": best_so_far},
         }
+        if world == 1 and headline and not args.no_side:
+            p.seed = 42
+            try:
+                out["side"] = {"hardties": side_kind(args, comm, fr, native, req, "hardties", begin, end, out["value"])}
+            except Exception as exc:  # (a side leg: its failure must not cost the bench line -- it is reported in it)
+                out["side"] = {"hardties": {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds, args.measure)
+            out["cpu_baseline"] = cpu_baseline(X, y, qid, p.to_dict(), args.cpu_seconds, args.measure, args.restarts_per_gpu)
         print(json.dumps(out))
         sys.stdout.flush()
 

@@ -152,6 +152,37 @@ def test_verify_path_equals_exact_kernel_at_full_size(big, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["mslr", "tiesmix"])
+def test_resident_training_equals_the_oracle_at_the_30k_shape(kind):
+    """The kernel bench.py times (linesearch_verify_kernel on RESIDENT sums, default path) against the ORACLE, not
+    against another HIP kernel, on the whole 3.8 M x 136 matrix: after 25 resident ticks every restart's best_score
+    must be what the CPU restatement of evaluate_mean (src/evaluators.rs:173-224, src/dense_dataset.rs:67-76) gives
+    for that restart's best weights, bit for bit (oracle in the HIP path's 256-query summation shape).  tiesmix =
+    duplicate rows and integer columns, i.e. the variant with duplicate groups."""
+    n, d, q, seed = bench.SHAPES["30k"]
+    if kind == "mslr":
+        _, X, y, qid, g = _shape("30k")
+    else:
+        X, y, qid = bench.gen_mslr_shaped(seed, n, d, q, kind)
+        g = fr.CDataset.from_numpy(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    req.params.seed, req.params.quiet, req.params.num_restarts = 5, True, 4
+    run = native.CoordinateAscentRun(g, req)
+    run.step(25)
+    st = run.state()
+    run.close()
+    if not os.environ.get("FR_LS_EXACT"):
+        assert st["stats"]["verify_pairs"] > 0 and st["stats"]["exact_groups"] * 2 < st["stats"]["groups"], st["stats"]
+    c = o.Dataset(X, y, qid)
+    o.set_mean_segment(o.DEVICE_MEAN_SEGMENT)
+    try:
+        for r in st["restarts"]:
+            assert c.evaluate_mean("ndcg@10", np.asarray(r["weights"])) == r["score"], (kind, r["restart_id"])
+    finally:
+        o.set_mean_segment(0)
+
+
+@pytest.mark.parametrize("kind", ["mslr", "tiesmix"])
 def test_every_resident_verify_variant_runs_at_the_30k_shape(kind, monkeypatch):
     """Round 5: one variant of linesearch_verify_kernel (K = 10, K + 2 keys) faulted at the 30K shape only -- an inline-asm
     output overlapped the address register of the scalar load behind it, which shows when that load waits to issue, i.e.
