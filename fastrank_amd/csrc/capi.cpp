@@ -1281,7 +1281,7 @@ const void* fr_evaluate_candidates(const CDataset* dataset, const CQRel* qrel, c
             if (n_cand[g] == 0 || n_cand[g] > 64 || features[g] >= d)
                 fr::fail_str("fr_evaluate_candidates: malformed group");
         const bool topk = dev.linesearch_supported(ev.measure, ev.depth);
-        const bool full = !topk && dev.fullrank_supported(ev.measure, ev.depth) && !getenv("FR_FORCE_GENERIC");
+        const bool full = !topk && dev.fullrank_supported(ev.measure, ev.depth) && !frdev::path_env("FR_FORCE_GENERIC");
         if (topk || full) {
             std::vector<frdev::LineGroup> groups(n_groups);
             for (size_t g = 0; g < n_groups; g++) {

@@ -18,6 +18,26 @@
 
 namespace frdev {
 
+// Environment switches, three kinds (INTEGRATION.md lists the first):
+//   * runtime configuration of the shipped library is read with std::getenv where it is used: FR_DEVICES, FR_RESTART_QUEUE,
+//     FR_RESTART_SLOTS, FR_MIN_RESTARTS_PER_DEVICE, FR_XCOL, FR_VERIFY_ORDER, FR_LS_EXACT, FR_VERIFY_AUDIT, FR_LS_PIPELINE,
+//     FR_UPLOAD_TIMING, FR_HOST_TIMING;
+//   * path_env: selectors of ANOTHER BIT-EXACT path (the exact kernels instead of bound-and-verify, the generic sort
+//     evaluator instead of the fused one, tiles instead of resident sums, ...).  The parity tests use them to reach every
+//     path with the same inputs; whatever they are set to, results are the reference's;
+//   * pricing_env: timing experiments and tuning sweeps, some of which return WRONG numbers on purpose (a kernel phase
+//     skipped to price the rest).  They exist only in a library built with -DFR_PRICING (FR_BUILD_FLAGS=-DFR_PRICING):
+//     the shipped library cannot be talked into wrong scores through its environment.
+const char* path_env(const char* name);
+inline const char* pricing_env(const char* name) {
+#ifdef FR_PRICING
+    return path_env(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 enum Measure : int { M_NDCG = 0, M_AP = 1, M_RR = 2 };
 
 // Error bound E >= |R - sum_j x_j v_j| of a trainer's resident sums, u = 2^-53, T from column

@@ -466,7 +466,7 @@ struct DatasetView {
         std::string err;
         bool all = true;
         DatasetView* owner = matrix_owner(&all);
-        if (owner != this && !getenv("FR_VIEW_COPIES")) {  // (FR_VIEW_COPIES=1: every view tiles its own matrix, as in round 1)
+        if (owner != this && !frdev::path_env("FR_VIEW_COPIES")) {  // (FR_VIEW_COPIES=1: every view tiles its own matrix, as in round 1)
             std::shared_ptr<frdev::DeviceDataset> pdev = owner->device_ptr();
             if (all) {
                 dev = pdev;  // same documents: the parent's device dataset as it is
@@ -957,7 +957,7 @@ class CATrainer {
         }
         refill_min_ = std::max<size_t>(1, rs_.size() / 8);
         bool can_fused = dev.linesearch_supported(ev_.measure, ev_.depth);
-        bool can_fullrank = dev.fullrank_supported(ev_.measure, ev_.depth) && !getenv("FR_FORCE_GENERIC");
+        bool can_fullrank = dev.fullrank_supported(ev_.measure, ev_.depth) && !frdev::path_env("FR_FORCE_GENERIC");
         if (shard_.allreduce) {
             // Query shards: what a shard's device form supports depends on that shard's data (a non-finite
             // feature, a query beyond the rank-table size, the number of gain classes), and the vector each
@@ -981,13 +981,13 @@ class CATrainer {
         // Resident base sums for the bound-and-verify kernel (device.hpp LineGroup): one slot per restart holds
         // R ~ sum_j x_j * best_w_j for every document, so a tick reads 24 bytes per document and restart instead
         // of the whole feature row.  FR_LS_RESIDENT=0 turns it off (every tick then forms the sums from the tiles).
-        const char* res_env = getenv("FR_LS_RESIDENT");
+        const char* res_env = frdev::path_env("FR_LS_RESIDENT");
         if ((fused_ || fullrank_) && !(res_env && res_env[0] == '0')) {
             std::string _err;
             res_owner_ = dev.resident_reserve(R, &_err);
             if (res_owner_ != 0) {
                 resident_ = true;
-                if (const char* e = getenv("FR_RESIDENT_REFRESH")) res_refresh_ = (uint32_t)std::max(1, atoi(e));
+                if (const char* e = frdev::path_env("FR_RESIDENT_REFRESH")) res_refresh_ = (uint32_t)std::max(1, atoi(e));
                 for (size_t k = 0; k < R; k++) rs_[k].slot = (int)k;
                 refresh_resident(all);
             }

@@ -177,7 +177,7 @@ class RFTrainer {
                 stats_.sorted_items += x.sorted_items;
             }
         }
-        if (getenv("FR_RF_TIMING"))
+        if (frdev::pricing_env("FR_RF_TIMING"))
             fprintf(stderr, "[rf] sample %.2f s, begin %.2f s, levels %.2f s, select %.2f s, split %.2f s, weights %.2f s\n", stats_.t_sample,
                     stats_.t_begin, stats_.t_level, stats_.t_select, stats_.t_split, stats_.t_weights);
         if (!p_.quiet) printf("-----------------------\n");
@@ -207,7 +207,7 @@ class RFTrainer {
             const size_t free_b = frdev::device_free_bytes();
             if (free_b != 0) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, free_b / 5 * 2));
         }
-        if (const char* e = getenv("FR_RF_BATCH_BYTES")) budget = std::max<size_t>(1 << 20, (size_t)atoll(e));
+        if (const char* e = frdev::path_env("FR_RF_BATCH_BYTES")) budget = std::max<size_t>(1 << 20, (size_t)atoll(e));
         struct EndGuard {  // the batch buffers (GBs) go back to the device also when a batch fails
             frdev::DeviceDataset& d;
             ~EndGuard() { d.rf_end(); }
@@ -352,7 +352,7 @@ class RFTrainer {
             // SquaredError evaluates a candidate by summing the gains of both sides in the segment's order -- the same sums
             // compute_output of the children divides (random_forest.rs:32-41, 395-398): taken from the chosen candidate, no
             // second pass over the node (FR_RF_CHILDSUM=1: the separate pass, for comparison)
-            const bool force_childsum = getenv("FR_RF_CHILDSUM") != nullptr;
+            const bool force_childsum = frdev::path_env("FR_RF_CHILDSUM") != nullptr;
             const bool sums_from_cands = p_.split_method == 0 && !force_childsum;
             std::vector<Pending> pend;
             const uint32_t km1 = k >= 2 ? k - 1 : 0;

@@ -34,6 +34,22 @@ def test_library_exports_every_declared_symbol():
         assert name in syms
 
 
+def test_pricing_switches_are_not_in_the_shipped_library():
+    """Timing ablations that return wrong numbers on purpose (a kernel phase skipped: FR_TREE_NOWALK, FR_TREE_NOSTAGE,
+    FR_LS_DEBUG) and the tuning sweeps exist only in a -DFR_PRICING build (csrc/device.hpp: pricing_env): the default
+    library does not even hold their names, so its environment cannot talk it into wrong scores."""
+    if os.environ.get("FR_BUILD_FLAGS", "").find("FR_PRICING") >= 0:
+        pytest.skip("pricing build")
+    blob = open(clib._build.LIB_PATH, "rb").read()
+    for name in (b"FR_TREE_NOWALK", b"FR_TREE_NOSTAGE", b"FR_LS_DEBUG", b"FR_ORDER_KAPPA", b"FR_RANK_PERIOD", b"FR_TREE_NMAX"):
+        assert name not in blob, name
+    assert b"FR_LS_EXACT" in blob  # (a supported switch: the exact kernels alone, same results)
+    n = 0
+    for fn in os.listdir(os.path.join(ROOT, "fastrank_amd", "csrc")):
+        n += sum(1 for line in open(os.path.join(ROOT, "fastrank_amd", "csrc", fn), errors="replace") if "getenv" in line)
+    assert n <= 20, n
+
+
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fastrank_amd")):
         for fn in files:

@@ -674,6 +674,30 @@ def test_tree_rank_kernel(mslr_small, small):
     assert "tree_rank_kernel" not in used and np.array_equal(got, c.score_ensemble(deep, [1.0, 0.5]))
 
 
+def test_wrong_answer_switches_do_nothing_in_the_shipped_library(mslr_small, monkeypatch):
+    """FR_TREE_NOWALK / FR_TREE_NOSTAGE / FR_LS_DEBUG=1 skip a kernel phase to price the rest and return garbage: they
+    are compiled in only with -DFR_PRICING.  In the default build the environment cannot change a score."""
+    if "FR_PRICING" in os.environ.get("FR_BUILD_FLAGS", ""):
+        pytest.skip("pricing build")
+    X, y, qid, g, c = mslr_small
+    rng = np.random.default_rng(31)
+    trees = [_rand_tree(rng, X, 7) for _ in range(40)]
+    weights = rng.uniform(-1.0, 1.0, len(trees)).tolist()
+    for name in ("FR_TREE_NOWALK", "FR_TREE_NOSTAGE", "FR_LS_DEBUG"):
+        monkeypatch.setenv(name, "1")
+    got, used = _tree_kernels_used(_ensemble(trees, weights), g)
+    assert used == {"tree_rank_kernel"} and np.array_equal(got, c.score_ensemble(trees, weights))
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = "ndcg@10"
+    req.params.seed, req.params.quiet, req.params.num_restarts = 3, True, 2
+    run = native.CoordinateAscentRun(g, req)
+    run.step(3)
+    st = run.state()
+    run.close()
+    for r in st["restarts"]:
+        assert c.evaluate_mean("ndcg@10", np.asarray(r["weights"])) == r["score"]
+
+
 def test_tree_rank_kernel_slot_layouts(mslr_small):
     """Codes sit two slots to a 32-bit word and the constant slots follow the last feature's: forests over 1, 2, 3, 5
     and 7 distinct features (odd and even slot counts, the constant slots sharing / not sharing a word with a feature;
