@@ -473,6 +473,7 @@ def side_kind(args, comm, fr, native, req, kind, begin, end, headline_value):
             "of_headline": (value / headline_value) if headline_value else None,
             "redo_fraction": (vr / vp) if vp else None,
             "exact_group_share": (s1["exact_groups"] - s0["exact_groups"]) / max(1, s1["groups"] - s0["groups"]),
+            "chain_runs_per_visit": ((s1["chain_runs"] - s0["chain_runs"]) / (s1["chain_visits"] - s0["chain_visits"])) if s1.get("chain_visits", 0) > s0.get("chain_visits", 0) else None,
             "exact_kernel_ms_per_step": prof.get("linesearch_ndcg_kernel", {"total_ms": 0.0})["total_ms"] / psteps,
             "kernels_ms_per_step": {k: v["total_ms"] / psteps for k, v in prof.items()},
             "generate_s": gen_s}
@@ -732,7 +733,7 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
     upload_s = time.perf_counter() - t0
 
     totals = {"useful_evals": 0, "raw_evals": 0, "verify_pairs": 0, "verify_redone": 0, "exact_ticks": 0, "ticks": 0,
-              "line_searches": 0, "groups": 0, "exact_groups": 0, "verify_redo_entries": 0}
+              "line_searches": 0, "groups": 0, "exact_groups": 0, "verify_redo_entries": 0, "chain_runs": 0, "chain_visits": 0, "rank_slots_on": 0, "rank_slots_off": 0}
     jobs = {"finished": 0}
 
     def add_stats(stats):
@@ -1142,6 +1143,10 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
                 # 16-candidate slices the exact kernel recomputed per listed (query, group) pair (4 = all of a 51-candidate group)
                 "redo_slices_per_pair": ((s1["verify_redo_entries"] - s0["verify_redo_entries"]) / vr) if vr else None,
                 "exact_kernel_ms_per_step": exact["total_ms"] / max(1, prof_steps),
+                # documents that made a wave of the verify kernel run its insertion chain, per (document, group) visit (device counter)
+                "chain_runs_per_visit": ((s1["chain_runs"] - s0["chain_runs"]) / (s1["chain_visits"] - s0["chain_visits"])) if s1["chain_visits"] > s0["chain_visits"] else None,
+                # restarts (all jobs of this process so far) whose R-rank tables were found worth keeping / not worth it by that counter
+                "rank_slots_on_off": [s1b["rank_slots_on"], s1b["rank_slots_off"]],
             },
             "per_launch_overlapped": {"avg_launch_ms": ls["avg_ms"], "launches": ls["launches"],
                                       "note": "HIP-event durations of pipelined launches (three sets in flight, so they overlap), from {} "

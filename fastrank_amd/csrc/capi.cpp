@@ -153,6 +153,10 @@ Value stats_to_json(const fr::TrainStats& s) {
     o.set("exact_ticks", Value::uint(s.exact_ticks));
     o.set("exact_groups", Value::uint(s.exact_groups));
     o.set("verify_redo_entries", Value::uint(s.verify_redo_entries));
+    o.set("chain_runs", Value::uint(s.chain_runs));
+    o.set("chain_visits", Value::uint(s.chain_visits));
+    o.set("rank_slots_on", Value::uint(s.rank_slots_on));
+    o.set("rank_slots_off", Value::uint(s.rank_slots_off));
     o.set("line_searches", Value::uint(s.line_searches));
     o.set("audit_values", Value::uint(s.audit_values));
     o.set("audit_mismatches", Value::uint(s.audit_mismatches));
@@ -502,6 +506,8 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
         total.verify_pairs += stats[i].verify_pairs, total.verify_redone += stats[i].verify_redone;
         total.line_searches += stats[i].line_searches, total.exact_ticks += stats[i].exact_ticks;
         total.exact_groups += stats[i].exact_groups, total.verify_redo_entries += stats[i].verify_redo_entries;
+        total.chain_runs += stats[i].chain_runs, total.chain_visits += stats[i].chain_visits;
+        total.rank_slots_on += stats[i].rank_slots_on, total.rank_slots_off += stats[i].rank_slots_off;
         total.audit_values += stats[i].audit_values, total.audit_mismatches += stats[i].audit_mismatches;
     }
     std::sort(hist.begin(), hist.end(), [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });

@@ -192,6 +192,10 @@ class DeviceDataset {
     // pairs undecided goes there for 4, 8, 16 line searches; the other groups of the tick stay on the verify kernel), and
     // the (query, group, 16-candidate slice) entries the verify kernel listed for recomputation
     void routing_counters(unsigned long long* exact_groups, unsigned long long* redo_entries) const;
+    // NDCG@k verify kernel: documents that made a wave run its insertion chain, and the (document, group) visits they are out of
+    // ... and the restarts whose R ranks were found worth keeping / not worth it (device_dataset.inc: slot_rank_mode)
+    void chain_counters(unsigned long long* runs, unsigned long long* visits, unsigned long long* ranked_on = nullptr,
+                        unsigned long long* ranked_off = nullptr) const;
     // FR_VERIFY_AUDIT=1: values re-derived by the exact kernel after a bound-and-verify line search / how many differed
     void audit_counters(unsigned long long* values, unsigned long long* mismatches) const;
     // --- full-ranking line search (AP, RR, NDCG of any depth): scores kernel + rank-counting kernel ----

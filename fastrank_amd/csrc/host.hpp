@@ -800,6 +800,8 @@ struct TrainStats {
     uint64_t exact_ticks = 0;  // line searches evaluated by the exact kernels alone (every group routed there / after a tick with > 25 % redone pairs)
     uint64_t exact_groups = 0;         // NDCG@k: group line searches routed to the exact kernel (of `groups`)
     uint64_t verify_redo_entries = 0;  // NDCG@k: (query, group, 16-candidate slice) entries the exact kernel recomputed
+    uint64_t chain_runs = 0, chain_visits = 0;  // NDCG@k verify kernel: insertion-chain runs out of (document, group) visits
+    uint64_t rank_slots_on = 0, rank_slots_off = 0;  // restarts whose R ranks were found worth keeping / not (chain runs of their first line searches)
     uint32_t devices = 1;      // devices train_model spread the restarts over (ticks = the longest device's)
     uint32_t refills = 0;      // times converged restarts handed their places to the next ids of the restart queue
     int device = -1;           // ordinal this trainer ran on (per-device entries of train_model's statistics)
@@ -809,15 +811,21 @@ struct TrainStats {
 struct ExactTickCount {
     frdev::DeviceDataset& dev;
     TrainStats& st;
-    unsigned long long base, av0 = 0, am0 = 0, eg0 = 0, re0 = 0;
+    unsigned long long base, av0 = 0, am0 = 0, eg0 = 0, re0 = 0, cr0 = 0, cv0 = 0, on0 = 0, off0 = 0;
     ExactTickCount(frdev::DeviceDataset& d, TrainStats& s) : dev(d), st(s), base(d.exact_fallbacks()) {
         d.audit_counters(&av0, &am0);
         d.routing_counters(&eg0, &re0);
+        d.chain_counters(&cr0, &cv0, &on0, &off0);
     }
     ~ExactTickCount() {
-        unsigned long long av1 = 0, am1 = 0, eg1 = 0, re1 = 0;
+        unsigned long long av1 = 0, am1 = 0, eg1 = 0, re1 = 0, cr1 = 0, cv1 = 0, on1 = 0, off1 = 0;
         dev.audit_counters(&av1, &am1);
         dev.routing_counters(&eg1, &re1);
+        dev.chain_counters(&cr1, &cv1, &on1, &off1);
+        st.rank_slots_on += on1 - on0;
+        st.rank_slots_off += off1 - off0;
+        st.chain_runs += cr1 - cr0;
+        st.chain_visits += cv1 - cv0;
         st.exact_groups += eg1 - eg0;
         st.verify_redo_entries += re1 - re0;
         st.exact_ticks += dev.exact_fallbacks() - base;
