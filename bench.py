@@ -219,6 +219,8 @@ class ThreadHub:
         self.slots = [None] * world
         self.lock = threading.Lock()
         self.counters = {}
+        self.devices = list(range(world))  # device ordinal of every rank (run_threads sets it)
+        self.rccl = (None, None)
 
 
 class ThreadComm(SingleComm):
@@ -247,9 +249,29 @@ class ThreadComm(SingleComm):
         return [list(r) for r in self._exchange(list(row))]
 
     def gather_restarts(self, mine, num_restarts):
-        allr = sorted((r for part in self._exchange(list(mine)) for r in part), key=lambda r: r["restart_id"])
+        """The job's one exchange.  The rank threads share an address space, so the blocks meet in host memory; when every
+        rank drives a GPU of its own they ALSO go through ONE single-process RCCL all-gather over those GPUs
+        (native.rccl_allgather_restarts: ncclCommInitAll + a grouped ncclAllGather), and the selection then reads what RCCL
+        delivered -- which must equal the host gather bit for bit (an error otherwise, and an error, not a fallback, if RCCL
+        cannot run on N distinct GPUs).  Ranks that share a GPU keep the host gather, with the reason recorded."""
+        parts = self._exchange(list(mine))
+        allr = sorted((r for part in parts for r in part), key=lambda r: r["restart_id"])
         if [r["restart_id"] for r in allr] != list(range(num_restarts)):
             raise RuntimeError("gather_restarts: expected restarts 0..{} exactly once".format(num_restarts - 1))
+        if self.rank == 0:
+            from fastrank_amd import native
+            try:
+                rep, via = native.rccl_allgather_restarts(list(self.hub.devices), parts)
+                if via is not None and via != allr:
+                    raise RuntimeError("the restarts RCCL delivered differ from the host gather")
+                self.hub.rccl = (rep, None)
+            except BaseException as exc:
+                self.hub.rccl = (None, exc)
+        self.hub.bar.wait()
+        rep, exc = self.hub.rccl
+        if exc is not None:
+            raise RuntimeError("RCCL exchange failed: {}: {}".format(type(exc).__name__, exc))
+        self.rccl_report = rep
         return allr
 
     def steal_blocks(self, num_restarts, block):
@@ -679,6 +701,7 @@ def run_threads(args, fr, native):
     X, y, qid = gen_mslr_shaped(seed, n, d, q, args.data)  # one host copy, borrowed by every rank's dataset
     gen_s = time.perf_counter() - t0
     hub = ThreadHub(args.gpus)
+    hub.devices = list(devices)
     errors = []
 
     def body(rank):
@@ -918,6 +941,11 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
             "devices_seen": [int(r[12]) for r in rows],
             "best_score": best["score"],
             "model_sha1": hashlib.sha1(json.dumps(model.to_dict(), sort_keys=True).encode()).hexdigest(),
+            # did the exchange go through RCCL?  thread launcher: one single-process all-gather over the ranks' GPUs, compared
+            # with the host gather (null + reason when the ranks share a GPU); torch launcher: torch.distributed's backend
+            "rccl": (getattr(comm, "rccl_report", None) if threads_mode else
+                     {"ran": comm.backend == "nccl", "ranks": world, "via": "torch.distributed all_gather, backend {}".format(comm.backend),
+                      "reason": None if comm.backend == "nccl" else ("one rank: nothing to exchange" if world == 1 else getattr(comm, "note", None))}),
         }
         e2e_top = e2e["e2e_evals_per_s"]
         if rank == 0:

@@ -22,7 +22,7 @@ OBJ_DIR = os.path.join(_HERE, "build")
 LIB_PATH = os.path.join(_HERE, "libfastrank_amd.so")
 INCLUDE = os.path.join("..", "..", "include", "fastrank.h")
 DEVICE_INCS = ["device.hpp", "fullverify.hpp", "device_plumbing.inc", "kernels_score.inc", "kernels_tree.inc", "kernels_treerank.inc", "kernels_metric.inc",
-               "kernels_linesearch.inc", "kernels_chain.inc", "kernels_fillnet.inc", "kernels_order.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "kernels_rf.inc", "device_dataset.inc"]
+               "kernels_linesearch.inc", "kernels_chain.inc", "kernels_fillnet.inc", "kernels_order.inc", "kernels_verify.inc", "kernels_fullrank.inc", "kernels_rr.inc", "kernels_rf.inc", "device_dataset.inc", "rccl_exchange.inc"]
 FV_INCS = ["device.hpp", "fullverify.hpp", "kernels_sortnet.inc", "kernels_fullverify.inc"]
 HOST_INCS = ["device.hpp", "host.hpp", "loader.hpp", "rf_train.hpp", "json.hpp", INCLUDE]
 
@@ -137,7 +137,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
                 f.result()
     objs = [os.path.join(OBJ_DIR, o) for o, _, _, _ in units()]
     tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-lz"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

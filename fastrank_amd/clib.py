@@ -95,6 +95,10 @@ def _load():
         "fr_debug_restart_queue": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]),
         "fr_dataset_release_replicas": (sz, [vp]),
         "fr_debug_peer_copy": (vp, [C.c_int, C.c_int, sz]),
+        "fr_pack_restart_records": (vp, [C.c_char_p, sz, sz, vp]),
+        "fr_unpack_restart_records": (vp, [vp, sz, sz]),
+        "fr_rccl_allgather": (vp, [vp, sz, vp, sz, vp]),
+        "fr_debug_rccl_selftest": (vp, [C.c_int]),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(L, name)

@@ -139,8 +139,28 @@ std::vector<std::pair<std::string, std::vector<uint32_t>>> instances_by_query(co
     return out;
 }
 
+Value rccl_report_to_json(const frdev::RcclReport& r) {
+    Value o = Value::object();
+    o.set("ran", Value::boolean(r.ran));
+    o.set("ranks", Value::uint((uint64_t)r.ranks));
+    Value d = Value::array();
+    for (int x : r.devices) d.push(Value::uint((uint64_t)x));
+    o.set("devices", std::move(d));
+    o.set("block_doubles", Value::uint((uint64_t)r.block_doubles));
+    if (r.ran) {
+        o.set("us", Value::number(r.us));
+        o.set("first_us", Value::number(r.first_us));
+        o.set("init_us", Value::number(r.init_us));
+        o.set("matches_host_gather", Value::boolean(r.matches_host_gather));
+    } else {
+        o.set("reason", Value::string(r.reason));
+    }
+    return o;
+}
+
 Value stats_to_json(const fr::TrainStats& s) {
     Value o = Value::object();
+    if (s.rccl_set) o.set("rccl", rccl_report_to_json(s.rccl));
     o.set("useful_evals", Value::uint(s.useful_evals));
     o.set("raw_evals", Value::uint(s.raw_evals));
     o.set("ticks", Value::uint(s.ticks));
@@ -495,10 +515,32 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
     for (auto& th : pool) th.join();
     for (size_t i = 0; i < k; i++)
         if (errors[i]) std::rethrow_exception(errors[i]);
-    std::vector<fr::RestartResult> hist;
-    fr::TrainStats total = stats[0];
+    // ---- the job's one exchange.  Every entry of the device list contributes its restarts as a block of records; the
+    // blocks meet in host memory (the threads share an address space) AND, when the entries are distinct GPUs, in ONE
+    // RCCL all-gather across them (frdev::rccl_allgather: ncclCommInitAll over the list, a grouped ncclAllGather).  The
+    // selection below reads what RCCL delivered to rank 0, which must equal the host-side concatenation bit for bit; ranks
+    // that share a GPU (FR_DEVICES=0,0: contexts, not devices) cannot form a communicator and keep the host gather, with the
+    // reason recorded.  With N distinct GPUs a failed exchange fails the request.
+    size_t dim = 0, cap = 1;
     for (size_t i = 0; i < k; i++) {
-        hist.insert(hist.end(), parts[i].begin(), parts[i].end());
+        cap = std::max(cap, parts[i].size());
+        for (const auto& h : parts[i]) dim = std::max(dim, h.weights.size());
+    }
+    const size_t block_len = cap * fr::restart_record_len(dim);
+    std::vector<double> blocks(k * block_len);
+    for (size_t i = 0; i < k; i++) fr::pack_restart_records(parts[i], cap, dim, blocks.data() + i * block_len);
+    frdev::RcclReport rccl;
+    std::vector<double> via_rccl;
+    {
+        std::string err;
+        if (!frdev::rccl_allgather(pl.devs, blocks.data(), block_len, &via_rccl, &rccl, &err)) fr::fail_str(err);
+    }
+    const std::vector<double>& exchanged = rccl.ran ? via_rccl : blocks;
+    std::vector<fr::RestartResult> hist = fr::unpack_restart_records(exchanged.data(), k * cap, dim, R);
+    fr::TrainStats total = stats[0];
+    total.rccl_set = true;
+    total.rccl = rccl;
+    for (size_t i = 0; i < k; i++) {
         if (i == 0) continue;
         total.useful_evals += stats[i].useful_evals, total.raw_evals += stats[i].raw_evals;
         total.ticks = std::max(total.ticks, stats[i].ticks), total.groups += stats[i].groups;
@@ -510,10 +552,6 @@ fr::Model train_ca_devices(const std::shared_ptr<fr::DatasetView>& view, const P
         total.rank_slots_on += stats[i].rank_slots_on, total.rank_slots_off += stats[i].rank_slots_off;
         total.audit_values += stats[i].audit_values, total.audit_mismatches += stats[i].audit_mismatches;
     }
-    std::sort(hist.begin(), hist.end(), [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });
-    if (hist.size() != R) fr::fail_str("internal error: the devices trained " + std::to_string(hist.size()) + " of " + std::to_string(R) + " restarts");
-    for (uint32_t r = 0; r < R; r++)
-        if (hist[r].restart_id != r) fr::fail_str("internal error: restart " + std::to_string(r) + " was not trained exactly once");
     total.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     total.devices = (uint32_t)k;
     total.device = -1;
@@ -1020,6 +1058,65 @@ const void* fr_debug_peer_copy(int src_device, int dst_device, size_t bytes) {
     });
 }
 
+// a JSON list of {"restart_id","score","weights"} (what fr_train_model_shard / fr_ca_state return)
+static std::vector<fr::RestartResult> restarts_from_json_text(const std::string& text) {
+    Value v = parse_json_or_fail(text);
+    if (!v.is_array()) fr::fail_raw("Error(\"invalid type: expected a sequence\", line: 1, column: 1)");
+    std::vector<fr::RestartResult> hist;
+    for (const auto& r : v.arr) {
+        fr::RestartResult h;
+        h.restart_id = (uint32_t)fr::json_u64(fr::json_field(r, "restart_id"), "restart_id");
+        h.score = fr::json_f64(fr::json_field(r, "score"), "score");
+        for (const auto& x : fr::json_field(r, "weights").arr) h.weights.push_back(fr::json_f64(x, "weights"));
+        hist.push_back(std::move(h));
+    }
+    return hist;
+}
+
+// The exchange records (host.hpp: pack_restart_records) for callers that gather outside the library.
+const void* fr_pack_restart_records(const void* restarts_json, size_t cap, size_t dim, double* out) {
+    return status_call([&]() {
+        if (out == nullptr) fr::fail_str("fr_pack_restart_records: null output buffer");
+        fr::pack_restart_records(restarts_from_json_text(accept_str("restarts_json", restarts_json)), cap, dim, out);
+    });
+}
+
+const void* fr_unpack_restart_records(const double* records, size_t n_records, size_t dim) {
+    return json_call([&]() {
+        if (records == nullptr && n_records > 0) fr::fail_str("fr_unpack_restart_records: null input buffer");
+        return frjson::dump(restarts_to_json(fr::unpack_restart_records(records, n_records, dim)));
+    });
+}
+
+// One single-process RCCL all-gather of `n` blocks of block_len doubles over `devices` (rccl_exchange.inc): out (optional)
+// receives rank 0's gathered buffer, n * block_len doubles.  Returns the report as JSON ({"ran": false, "reason"} when it
+// does not apply), or the error envelope when N distinct GPUs were named and the exchange failed.
+const void* fr_rccl_allgather(const int* devices, size_t n, const double* blocks, size_t block_len, double* out) {
+    return json_call([&]() {
+        if ((devices == nullptr || blocks == nullptr) && n > 0) fr::fail_str("fr_rccl_allgather: null argument");
+        std::vector<int> devs(devices, devices + n);
+        frdev::RcclReport rep;
+        std::vector<double> got;
+        std::string err;
+        if (!frdev::rccl_allgather(devs, blocks, block_len, &got, &rep, &err)) fr::fail_str(err);
+        if (rep.ran && out != nullptr) std::memcpy(out, got.data(), got.size() * sizeof(double));
+        return frjson::dump(rccl_report_to_json(rep));
+    });
+}
+
+// The same call sequence on ONE device (a one-rank communicator): librccl.so opens, its symbols bind, ncclCommInitAll /
+// grouped ncclAllGather / ncclCommDestroy run and the data comes back.  What a one-GPU box can check of the exchange.
+const void* fr_debug_rccl_selftest(int device) {
+    return json_call([&]() {
+        std::vector<double> block(16), got;
+        for (size_t i = 0; i < block.size(); i++) block[i] = 0.5 + (double)i;
+        frdev::RcclReport rep;
+        std::string err;
+        if (!frdev::rccl_allgather(std::vector<int>(1, device), block.data(), block.size(), &got, &rep, &err, 1)) fr::fail_str(err);
+        return frjson::dump(rccl_report_to_json(rep));
+    });
+}
+
 int fr_set_device(int ordinal) {
     std::string err;
     if (!frdev::set_device(ordinal, &err)) return 1;
@@ -1139,16 +1236,7 @@ void fr_ca_free(void* trainer) { delete (FrTrainer*)trainer; }
 
 const CResult* fr_select_model(const void* restarts_json, int output_ensemble) {
     return c_call<CModel>([&]() {
-        Value v = parse_json_or_fail(accept_str("restarts_json", restarts_json));
-        if (!v.is_array()) fr::fail_raw("Error(\"invalid type: expected a sequence\", line: 1, column: 1)");
-        std::vector<fr::RestartResult> hist;
-        for (const auto& r : v.arr) {
-            fr::RestartResult h;
-            h.restart_id = (uint32_t)fr::json_u64(fr::json_field(r, "restart_id"), "restart_id");
-            h.score = fr::json_f64(fr::json_field(r, "score"), "score");
-            for (const auto& x : fr::json_field(r, "weights").arr) h.weights.push_back(fr::json_f64(x, "weights"));
-            hist.push_back(std::move(h));
-        }
+        std::vector<fr::RestartResult> hist = restarts_from_json_text(accept_str("restarts_json", restarts_json));
         // restart order defines "last maximum" (src/coordinate_ascent.rs:244-251)
         std::stable_sort(hist.begin(), hist.end(),
                          [](const fr::RestartResult& a, const fr::RestartResult& b) { return a.restart_id < b.restart_id; });

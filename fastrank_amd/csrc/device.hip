@@ -33,6 +33,8 @@
 #include "fullverify.hpp"
 
 #include <cstring>
+#include <dlfcn.h>
+#include <unistd.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -63,5 +65,6 @@ namespace frdev {
 #include "kernels_rr.inc"
 #include "kernels_rf.inc"
 #include "device_dataset.inc"
+#include "rccl_exchange.inc"
 
 }  // namespace frdev

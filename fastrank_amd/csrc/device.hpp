@@ -256,6 +256,20 @@ void profile_reset();
 std::vector<KernelStat> profile_stats();
 bool device_synchronize(std::string* err);
 // one timed device-to-device copy src -> dst as replicate() makes them (device_plumbing.inc)
+// The job's one exchange as a single-process RCCL all-gather over `devices` (rccl_exchange.inc): rank i contributes
+// blocks[i * block_len .. (i + 1) * block_len), every rank receives all blocks in rank order; *gathered = rank 0's buffer.
+// rep->ran = false with a reason when it does not apply (one rank; ranks sharing a GPU); with N distinct GPUs any failure --
+// and any gathered buffer that differs from the blocks -- returns false.
+struct RcclReport {
+    bool ran = false, matches_host_gather = false;
+    int ranks = 0;
+    std::vector<int> devices;
+    size_t block_doubles = 0;
+    double init_us = 0.0, first_us = 0.0, us = 0.0;  // ncclCommInitAll; the first all-gather (lazy set-up included); the second
+    std::string reason;                               // why it did not run
+};
+bool rccl_allgather(const std::vector<int>& devices, const double* blocks, size_t block_len, std::vector<double>* gathered, RcclReport* rep,
+                    std::string* err, size_t min_ranks = 2);  // (min_ranks = 1: the self-test -- a one-rank communicator really runs)
 bool peer_copy_probe(int src, int dst, size_t bytes, int* can_access, int* enabled, double* ms, std::string* err);
 size_t device_free_bytes();
 // page-locked host memory (nullptr when none is left: the caller falls back to ordinary memory); for staging uploads that

@@ -784,6 +784,45 @@ struct RestartResult {
     std::vector<double> weights;
 };
 
+// The exchange records of the job's one all-gather (src/coordinate_ascent.rs:232-252 selects from them): a
+// rank's restarts as a fixed-size block of `cap` records of 3 + d doubles -- valid (1.0 / 0.0 padding), restart id, score,
+// weights[d] -- the same layout native.gather_restarts puts through torch.distributed and rccl_allgather puts through RCCL.
+inline size_t restart_record_len(size_t d) { return 3 + d; }
+inline void pack_restart_records(const std::vector<RestartResult>& mine, size_t cap, size_t d, double* out) {
+    if (mine.size() > cap) fail_str("pack_restart_records: " + std::to_string(mine.size()) + " restarts for a block of " + std::to_string(cap));
+    const size_t rl = restart_record_len(d);
+    std::fill(out, out + cap * rl, 0.0);
+    for (size_t k = 0; k < mine.size(); k++) {
+        if (mine[k].weights.size() > d) fail_str("pack_restart_records: a restart has more weights than the record holds");
+        double* r = out + k * rl;
+        r[0] = 1.0;
+        r[1] = (double)mine[k].restart_id;
+        r[2] = mine[k].score;
+        std::copy(mine[k].weights.begin(), mine[k].weights.end(), r + 3);
+    }
+}
+// every valid record of `n` records, in restart order; each id must occur exactly once when `expect` > 0 (= the ids 0..expect-1)
+inline std::vector<RestartResult> unpack_restart_records(const double* in, size_t n, size_t d, size_t expect = 0) {
+    const size_t rl = restart_record_len(d);
+    std::vector<RestartResult> out;
+    for (size_t k = 0; k < n; k++) {
+        const double* r = in + k * rl;
+        if (r[0] != 1.0) continue;
+        RestartResult x;
+        x.restart_id = (uint32_t)r[1];
+        x.score = r[2];
+        x.weights.assign(r + 3, r + 3 + d);
+        out.push_back(std::move(x));
+    }
+    std::sort(out.begin(), out.end(), [](const RestartResult& a, const RestartResult& b) { return a.restart_id < b.restart_id; });
+    if (expect > 0) {
+        if (out.size() != expect) fail_str("internal error: the exchange carried " + std::to_string(out.size()) + " of " + std::to_string(expect) + " restarts");
+        for (size_t r = 0; r < expect; r++)
+            if (out[r].restart_id != r) fail_str("internal error: restart " + std::to_string(r) + " was not trained exactly once");
+    }
+    return out;
+}
+
 struct TrainStats {
     uint64_t useful_evals = 0;  // evaluate_mean calls the sequential reference would have made
     uint64_t raw_evals = 0;     // candidates actually evaluated (incl. speculative ones)
@@ -805,6 +844,9 @@ struct TrainStats {
     uint32_t devices = 1;      // devices train_model spread the restarts over (ticks = the longest device's)
     uint32_t refills = 0;      // times converged restarts handed their places to the next ids of the restart queue
     int device = -1;           // ordinal this trainer ran on (per-device entries of train_model's statistics)
+    // train_model over several devices: the exchange of the restarts' records as an RCCL all-gather (rccl_exchange.inc)
+    bool rccl_set = false;
+    frdev::RcclReport rccl;
 };
 
 // adds the exact-only line searches of a scope to the trainer's statistics (also when the scope unwinds)

@@ -257,6 +257,45 @@ def peer_copy(src_device: int, dst_device: int, nbytes: int = 256 << 20) -> Dict
     return _json_reply(_load().fr_debug_peer_copy(int(src_device), int(dst_device), int(nbytes)))
 
 
+def pack_restart_records(restarts: List[Dict], cap: int, dim: int) -> "np.ndarray":
+    """A rank's restarts as the fixed-size block of the job's one exchange: `cap` records of 3 + dim doubles -- valid, restart
+    id, score, weights (include/fastrank.h: fr_pack_restart_records; the library's own multi-device train_model packs with the
+    same code)."""
+    out = np.zeros((int(cap), 3 + int(dim)), dtype=np.float64)
+    _status(_load().fr_pack_restart_records(json.dumps(restarts).encode("utf-8"), int(cap), int(dim), out.ctypes.data))
+    return out
+
+
+def unpack_restart_records(records: "np.ndarray", dim: int) -> List[Dict]:
+    """The valid records of any number of blocks, as restarts in restart order."""
+    arr = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 3 + int(dim))
+    return _json_reply(_load().fr_unpack_restart_records(arr.ctypes.data, arr.shape[0], int(dim)))
+
+
+def rccl_allgather_restarts(devices: List[int], parts: List[List[Dict]]) -> Tuple[Dict, Optional[List[Dict]]]:
+    """The job's one exchange as ONE single-process RCCL all-gather over `devices` (one rank per entry; parts[i] = the restarts
+    rank i trained): (report, restarts).  report["ran"] is False with a "reason" when RCCL does not apply (one rank; ranks that
+    share a GPU) and restarts is then None; with N distinct GPUs a failure raises (include/fastrank.h: fr_rccl_allgather)."""
+    n = len(devices)
+    cap = max([1] + [len(p) for p in parts])
+    dim = max([0] + [len(r["weights"]) for p in parts for r in p])
+    blocks = np.stack([pack_restart_records(p, cap, dim) for p in parts]) if n else np.zeros((0, cap, 3 + dim))
+    out = np.empty_like(blocks)
+    devs = np.ascontiguousarray(devices, dtype=np.int32)
+    rep = _json_reply(_load().fr_rccl_allgather(devs.ctypes.data, n, blocks.ctypes.data, cap * (3 + dim), out.ctypes.data))
+    if not rep.get("ran"):
+        return rep, None
+    if not np.array_equal(out.view(np.uint64), blocks.view(np.uint64)):
+        raise RuntimeError("rccl_allgather_restarts: rank 0's gathered records differ from the blocks the ranks contributed")
+    return rep, unpack_restart_records(out, dim)
+
+
+def rccl_selftest(device: int = 0) -> Dict:
+    """A one-rank RCCL communicator on `device` through the library's exchange code (dlopen, ncclCommInitAll, grouped
+    ncclAllGather, compare, destroy): the report of fr_rccl_allgather."""
+    return _json_reply(_load().fr_debug_rccl_selftest(int(device)))
+
+
 def release_replicas(dataset: CDataset) -> int:
     """Frees the copies of the dataset train_model made on other devices / in other contexts; returns how many."""
     return int(_load().fr_dataset_release_replicas(dataset.pointer))

@@ -234,6 +234,22 @@ const void *fr_debug_restart_queue(uint32_t num_restarts, uint32_t n_workers, ui
  * JSON {"src","dst","bytes","can_access","enabled","ms","gbps"}.  A first-contact check of the peer path on a multi-GPU
  * node (bench.py --gpus N reports it per device pair); src == dst measures a copy inside one device. */
 const void *fr_debug_peer_copy(int src_device, int dst_device, size_t bytes);
+/* The exchange records of a job's single all-gather (what src/coordinate_ascent.rs:232-252 selects from): a
+ * rank's restarts as a fixed-size block of `cap` records of 3 + dim doubles -- valid (1.0; 0.0 = padding), restart id, score,
+ * weights[dim].  fr_pack_restart_records writes the block for a JSON list of {"restart_id","score","weights"} (returns NULL
+ * or an error envelope); fr_unpack_restart_records returns the valid records of n_records records as such a list, in
+ * restart order.  Same layout as native.gather_restarts (torch.distributed) and train_model's own fan-out. */
+const void *fr_pack_restart_records(const void *restarts_json, size_t cap, size_t dim, double *out);
+const void *fr_unpack_restart_records(const double *records, size_t n_records, size_t dim);
+/* ONE single-process RCCL all-gather over `devices` (ncclCommInitAll over the list, a grouped ncclAllGather; librccl.so is
+ * dlopen-ed, no link-time dependency): rank i contributes blocks[i * block_len ..], `out` (optional, n * block_len doubles)
+ * receives what rank 0 gathered.  JSON {"ran":true,"ranks","devices","us","first_us","init_us","matches_host_gather"}, or
+ * {"ran":false,"reason"} when it does not apply (one rank; ranks that share a GPU).  With n distinct GPUs a failure is an
+ * error envelope, not a fallback.  train_model's multi-device path runs it on the restarts' records itself
+ * (fr_last_train_stats: "rccl"). */
+const void *fr_rccl_allgather(const int *devices, size_t n, const double *blocks, size_t block_len, double *out);
+/* The same call sequence with a one-rank communicator on `device` (what a one-GPU box can run of it): same JSON. */
+const void *fr_debug_rccl_selftest(int device);
 /* Frees the device-to-device copies train_model made of this dataset on other devices / in other contexts (they are kept
  * with the dataset so that the next request reuses them; a node shared with other jobs may want the HBM back).  The
  * dataset's first device form stays.  Returns the number of copies released.  Views sampled from the dataset

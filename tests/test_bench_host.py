@@ -59,6 +59,7 @@ def test_thread_ranks_exchange_like_process_ranks():
 
     world = 3
     hub = bench.ThreadHub(world)
+    hub.devices = [0] * world  # three contexts on one GPU: the exchange stays in host memory, RCCL reports why it did not run
     out = [None] * world
 
     def body(rank):
@@ -71,7 +72,7 @@ def test_thread_ranks_exchange_like_process_ranks():
         blocks = list(c.steal_blocks(10, 3))
         c.barrier()
         blocks2 = list(c.steal_blocks(4, 4))  # (a second job gets its own counter)
-        out[rank] = (s, m, rows, [r["restart_id"] for r in allr], blocks, blocks2)
+        out[rank] = (s, m, rows, [r["restart_id"] for r in allr], blocks, blocks2, c.rccl_report)
 
     threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
     for t in threads:
@@ -79,13 +80,43 @@ def test_thread_ranks_exchange_like_process_ranks():
     for t in threads:
         t.join()
     assert all(o is not None for o in out)
-    for s, m, rows, ids, _, _ in out:
+    for s, m, rows, ids, _, _, rccl in out:
         assert s == [6.0, (0.1 + 0.2) + 0.30000000000000004] and m == [2.0]  # added in rank order: the same bits on every rank
         assert rows == [[0.0, 0.0], [1.0, 1.0], [2.0, 4.0]] and ids == list(range(7))
+        assert rccl["ran"] is False and rccl["ranks"] == 3 and "share device 0" in rccl["reason"]
     assert sorted(b for o in out for b in o[4]) == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert sorted(b for o in out for b in o[5]) == [(0, 4)]
     single = bench.SingleComm()
     assert single.allreduce([1.0], "sum") == [1.0] and list(single.steal_blocks(5, 2)) == [(0, 2), (2, 4), (4, 5)]
+
+
+def test_thread_ranks_on_distinct_gpus_must_exchange_through_rccl():
+    """with one GPU per rank thread the job's exchange goes through ONE single-process RCCL all-gather, and
+    when that cannot run it is an ERROR on every rank, not a silent host-memory gather.  This box has no GPU: two ranks that
+    name devices 0 and 1 must both fail loudly."""
+    import threading
+
+    from fastrank_amd import native
+    if native.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box without two GPUs (the multi-GPU form is tests/test_gpu_multidevice.py's)")
+    hub = bench.ThreadHub(2)
+    hub.devices = [0, 1]
+    errs = [None, None]
+
+    def body(rank):
+        c = bench.ThreadComm(hub, rank)
+        try:
+            c.gather_restarts([{"restart_id": rank, "score": 0.5, "weights": [1.0, 2.0]}], 2)
+        except RuntimeError as exc:
+            errs[rank] = str(exc)
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(e is not None and "RCCL exchange failed" in e for e in errs), errs
 
 
 def test_rccl_failure_is_an_error_only_when_every_rank_has_its_own_gpu():

@@ -50,6 +50,41 @@ def test_pricing_switches_are_not_in_the_shipped_library():
     assert n <= 20, n
 
 
+def test_exchange_records_round_trip_bit_for_bit():
+    """The records of the job's one all-gather (include/fastrank.h: fr_pack_restart_records): fixed-size blocks
+    of (valid, restart id, score, weights), padded with invalid records -- what train_model's multi-device path and
+    bench.py's thread ranks put through RCCL.  Packing and unpacking keep every bit (denormals, -0.0, ids up to 2^32 - 1), drop
+    the padding, and return restart order; the single-process RCCL call itself says why it does not apply here."""
+    rng = np.random.default_rng(5)
+    dim = 7
+    parts = []
+    ids = rng.permutation(11)
+    for rank, chunk in enumerate((ids[:5], ids[5:5], ids[5:])):  # (a rank without restarts contributes padding only)
+        parts.append([{"restart_id": int(i), "score": float(rng.random()), "weights": rng.uniform(-1, 1, dim).tolist()} for i in chunk])
+    parts[0][0]["weights"][:3] = [-0.0, 5e-324, 1.7976931348623157e308]
+    parts[2].append({"restart_id": 4294967295, "score": -0.0, "weights": [0.0] * dim})
+    cap = max(len(p) for p in parts)
+    blocks = np.stack([native.pack_restart_records(p, cap, dim) for p in parts])
+    assert blocks.shape == (3, cap, 3 + dim) and blocks[1].tolist() == np.zeros((cap, 3 + dim)).tolist()
+    assert (blocks[:, :, 0].sum(axis=1) == [len(p) for p in parts]).all()
+    got = native.unpack_restart_records(blocks, dim)
+    want = sorted((r for p in parts for r in p), key=lambda r: r["restart_id"])
+    assert [r["restart_id"] for r in got] == [r["restart_id"] for r in want]
+    for a, b in zip(got, want):
+        assert np.array_equal(np.array([a["score"]] + a["weights"]).view(np.uint64), np.array([b["score"]] + b["weights"]).view(np.uint64))
+    with pytest.raises(Exception, match="restarts for a block"):
+        native.pack_restart_records(parts[2], 2, dim)
+    # the RCCL call: not applicable on one rank / ranks that share a GPU (a reason, nothing run) ...
+    rep, via = native.rccl_allgather_restarts([0], [parts[0]])
+    assert rep["ran"] is False and via is None and "one rank" in rep["reason"]
+    rep, via = native.rccl_allgather_restarts([0, 0, 0], parts)
+    assert rep["ran"] is False and via is None and "share device 0" in rep["reason"] and rep["block_doubles"] == cap * (3 + dim)
+    # ... and an error, not a fallback, when the ranks name distinct GPUs and the exchange cannot run (no GPU on this box)
+    if native.device_count() < 3:
+        with pytest.raises(Exception, match="not visible"):
+            native.rccl_allgather_restarts([0, 1, 2], parts)
+
+
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fastrank_amd")):
         for fn in files:

@@ -56,6 +56,32 @@ def test_two_contexts_on_one_device_train_the_single_trainer_model(data, measure
     assert st2["restarts"] == 32 and st2["useful_evals"] == st1["useful_evals"]
     three, st3 = _train(g, req, "0,0,0")  # 11 + 11 + 10 restarts; the copies of the earlier run are reused
     assert three == one and st3["devices"] == 3
+    # the exchange: contexts that share a GPU cannot form an RCCL communicator -- host gather, with the reason on record
+    assert "rccl" not in st1
+    assert st2["rccl"]["ran"] is False and st2["rccl"]["ranks"] == 2 and "share device 0" in st2["rccl"]["reason"]
+
+
+def test_rccl_call_sequence_runs_on_this_gpu():
+    """librccl.so opens, its symbols bind, and a one-rank communicator's all-gather returns the block it was given."""
+    r = native.rccl_selftest(0)
+    assert r["ran"] is True and r["ranks"] == 1 and r["matches_host_gather"] is True and r["us"] > 0
+
+
+def test_distinct_gpus_exchange_through_one_rccl_all_gather(data):
+    """SURVEY.md 8e / BASELINE.json configs[3]: with one GPU per entry of the device list, the restarts' records go through
+    ONE single-process RCCL all-gather (csrc/rccl_exchange.inc) and the model is selected from what RCCL delivered.  Needs two
+    GPUs; the one-GPU box checks the raw call's refusal instead (an error, never a silent host gather)."""
+    X, y, qid, g = data
+    if native.device_count() < 2:
+        with pytest.raises(Exception, match="not visible"):
+            native.rccl_allgather_restarts([0, 1], [[{"restart_id": 0, "score": 0.5, "weights": [1.0]}], []])
+        pytest.skip("one GPU visible: the two-GPU exchange itself cannot run here")
+    req = _request("ndcg@10", 16)
+    one, _ = _train(g, req, "0")
+    two, st = _train(g, req, "0,1")
+    assert one == two and st["devices"] == 2
+    r = st["rccl"]
+    assert r["ran"] is True and r["ranks"] == 2 and r["devices"] == [0, 1] and r["matches_host_gather"] is True and r["us"] > 0
 
 
 def test_fan_out_matches_the_oracle_and_handles_ensembles_and_few_restarts(data):
