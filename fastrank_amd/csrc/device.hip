@@ -49,6 +49,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 
 namespace frdev {
 
