@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of full-ranking kernel builds on one box: tools/ab/fv_ab.sh "<flags A>" "<flags B>" ...   ("" = as committed)
+# (round 6: the tuning / ablation switches this script sets exist only in a pricing build -- csrc/device.hpp pricing_env)
+export FR_BUILD_FLAGS="${FR_BUILD_FLAGS:--DFR_PRICING}"; python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/fv
 run() {
   echo "=== build flags: [$1]"

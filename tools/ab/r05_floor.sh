@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 5: what the verify kernel costs WITHOUT its per-document loop (FR_LS_DEBUG=1: phase S, the tile steps, the queries' ends,
 # the prologue; nothing is listed for redo), next to the whole kernel -- lock step
+# (round 6: the tuning / ablation switches this script sets exist only in a pricing build -- csrc/device.hpp pricing_env)
+export FR_BUILD_FLAGS="${FR_BUILD_FLAGS:--DFR_PRICING}"; python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; TAG=${1:-r05floor}; O=gpurun_out/$TAG; mkdir -p $O
 one() {
   local lab=$1; shift

@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 5: variants of the visiting order by environment (no rebuild): kappa = inf (every lane walks the R copy: one address per
 # read), kappa = 0 (no lane does), ranks made once
+# (round 6: the tuning / ablation switches this script sets exist only in a pricing build -- csrc/device.hpp pricing_env)
+export FR_BUILD_FLAGS="${FR_BUILD_FLAGS:--DFR_PRICING}"; python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; TAG=${1:-r05var}; shift; O=gpurun_out/$TAG; mkdir -p $O
 KIND=${1:-mslr}
 one() {

@@ -2,6 +2,8 @@
 # round 5: where the wave-instructions of config 5's kernel go, per NODE STEP (one tree level of one
 # document): the whole kernel, without the walks (FR_TREE_NOWALK: staging the threshold ranks + streaming the forest), without
 # the staging (FR_TREE_NOSTAGE: garbage codes, same walks).  One counter pass each, kernel trace only.
+# (round 6: the tuning / ablation switches this script sets exist only in a pricing build -- csrc/device.hpp pricing_env)
+export FR_BUILD_FLAGS="${FR_BUILD_FLAGS:--DFR_PRICING}"; python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${1:-r05tree}; mkdir -p $O
 one() {
   local lab=$1; shift

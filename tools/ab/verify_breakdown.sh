@@ -1,6 +1,8 @@
 #!/bin/bash
 # VALU wave-instructions of linesearch_verify_kernel per (document, group) with and without phase K (FR_LS_DEBUG=1 skips the
 # per-document loop): how much of the kernel is the per-tile and per-query work around it?
+# (round 6: the tuning / ablation switches this script sets exist only in a pricing build -- csrc/device.hpp pricing_env)
+export FR_BUILD_FLAGS="${FR_BUILD_FLAGS:--DFR_PRICING}"; python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r04d
 one() {
   rm -rf gpurun_out/r04d/bd_$1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 6: the tuning / ablation switches this script sets exist only in a pricing build -- csrc/device.hpp pricing_env)
+export FR_BUILD_FLAGS="${FR_BUILD_FLAGS:--DFR_PRICING}"; python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/views
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "view or tree or sampl or ensemble or single_feature" 2>&1 | tail -4
 python tools/viewbench.py 2>&1 | tail -1 > gpurun_out/views/views_30k.json

@@ -2,7 +2,7 @@
 # After `gpurun -- tools/ab/r05_final.sh <tag>`: copy what the run left under gpurun_out/ into profiles/ (the judged copies).
 # usage (repo root, this container): bash tools/copy_evidence.sh r05
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cp gpurun_out/profiles_new/${TAG}_* profiles/
 cp gpurun_out/r04b/bench_final.json profiles/${TAG}_bench.json
 cp gpurun_out/r04b/bench.json profiles/${TAG}_bench_driver_form.json
