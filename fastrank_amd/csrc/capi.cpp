@@ -152,6 +152,7 @@ Value rccl_report_to_json(const frdev::RcclReport& r) {
         o.set("first_us", Value::number(r.first_us));
         o.set("init_us", Value::number(r.init_us));
         o.set("matches_host_gather", Value::boolean(r.matches_host_gather));
+        o.set("library", Value::string(r.library));
     } else {
         o.set("reason", Value::string(r.reason));
     }

@@ -267,6 +267,7 @@ struct RcclReport {
     size_t block_doubles = 0;
     double init_us = 0.0, first_us = 0.0, us = 0.0;  // ncclCommInitAll; the first all-gather (lazy set-up included); the second
     std::string reason;                               // why it did not run
+    std::string library;                              // the librccl.so that ran (next to this library's own HIP runtime)
 };
 bool rccl_allgather(const std::vector<int>& devices, const double* blocks, size_t block_len, std::vector<double>* gathered, RcclReport* rep,
                     std::string* err, size_t min_ranks = 2);  // (min_ranks = 1: the self-test -- a one-rank communicator really runs)

@@ -62,7 +62,11 @@ def test_two_contexts_on_one_device_train_the_single_trainer_model(data, measure
 
 
 def test_rccl_call_sequence_runs_on_this_gpu():
-    """librccl.so opens, its symbols bind, and a one-rank communicator's all-gather returns the block it was given."""
+    """librccl.so opens, its symbols bind, and a one-rank communicator's all-gather returns the block it was given -- also in
+    a process that has imported PyTorch, whose bundled librccl.so (on its own HIP / HSA runtime) a bare-name dlopen would
+    hand back: the library opens the one next to ITS runtime by absolute path (seen failing as 'unhandled cuda error' behind
+    the full-size tests, which import torch for the gather)."""
+    import torch  # noqa: F401  (the hostile case on purpose)
     r = native.rccl_selftest(0)
     assert r["ran"] is True and r["ranks"] == 1 and r["matches_host_gather"] is True and r["us"] > 0
 
