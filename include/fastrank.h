@@ -148,7 +148,10 @@ const CResult *fr_select_model(const void *restarts_json, int output_ensemble);
 /* JSON stats of the most recent train_model / fr_train_model_shard call in this process:
  * {"useful_evals","raw_evals","ticks","groups","seconds","path","restarts","verify_pairs","verify_redone",
  *  "exact_ticks","exact_groups","verify_redo_entries","line_searches","audit_values","audit_mismatches","devices",
- *  "refills"} and, after a call that ran
+ *  "refills","chain_runs","chain_visits","rank_slots_on","rank_slots_off"} (chain_*: documents that made the NDCG@k verify
+ * kernel run its insertion chain, out of (document, group) visits -- the kernel's own counter; rank_slots_*: restarts whose
+ * R-rank upkeep that counter switched on again / off) and, after a call that spread over several devices, "rccl": the report
+ * of the exchange (fr_rccl_allgather below); and, after a call that ran
  * on several devices, "per_device": the same object for every entry of the device list (its "device", "restarts",
  * "ticks", "seconds", "refills": times converged restarts handed their places to ids from the shared restart queue)
  * (path: "fused_linesearch" | "fused_fullrank" | "generic_sort"; verify_*: (query, group) pairs evaluated by the

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/fuzz; TAG=${1:-r05}
 {
-echo "# tools/fuzz_parity.py (device trainer vs oracle, bit for bit), round-5 sources"
+echo "# tools/fuzz_parity.py (device trainer vs oracle, bit for bit), round-6 sources"
 python tools/fuzz_parity.py --iters 1500 --seed 501 2>&1 | tail -2
 echo "# full-ranking measures only, query lengths spread over all size classes (--long)"
 python tools/fuzz_parity.py --iters 800 --seed 502 --measures ndcg,map,ndcg@30,ndcg@100,ndcg,map --long 2>&1 | tail -2
