@@ -13,12 +13,15 @@ g = fr.CDataset.from_numpy(X, y, qid)
 req = fr.TrainRequest.coordinate_ascent(); req.measure = "ndcg@10"
 p = req.params; p.num_restarts, p.seed, p.quiet = 32, 42, True
 run = native.CoordinateAscentRun(g, req)
-prev = run.state()["stats"]; rates = []; times = []
+prev = run.state()["stats"]; rates = []; times = []; redo = []
 for t in range(ticks):
     t0 = time.perf_counter(); run.step(1); native.synchronize(); times.append((time.perf_counter() - t0) * 1e3)
     st = run.state()["stats"]
     dv = st["chain_visits"] - prev["chain_visits"]
-    rates.append((st["chain_runs"] - prev["chain_runs"]) / dv if dv else float("nan")); prev = st
+    rates.append((st["chain_runs"] - prev["chain_runs"]) / dv if dv else float("nan"))
+    dp = st["verify_pairs"] - prev["verify_pairs"]
+    redo.append((st["verify_redone"] - prev["verify_redone"]) / dp if dp else float("nan")); prev = st
 run.close()
 print(kind, "order" if not os.environ.get("FR_VERIFY_ORDER") else "storage", "chain runs per visit by tick:", " ".join("%.3f" % r for r in rates))
 print(kind, "ms per single-stepped tick:", " ".join("%.2f" % x for x in times))
+print(kind, "share of (query, group) pairs redone by the exact kernel:", " ".join("%.4f" % x for x in redo))
