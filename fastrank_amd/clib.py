@@ -99,6 +99,7 @@ def _load():
         "fr_unpack_restart_records": (vp, [vp, sz, sz]),
         "fr_rccl_allgather": (vp, [vp, sz, vp, sz, vp]),
         "fr_debug_rccl_selftest": (vp, [C.c_int]),
+        "fr_debug_walk_tiles": (vp, [vp, vp, vp, sz, vp, vp, sz, sz]),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(L, name)

@@ -1105,6 +1105,34 @@ const void* fr_rccl_allgather(const int* devices, size_t n, const double* blocks
     });
 }
 
+// The walk tiles the device form of a dataset would get for these runs and queries (frdev::build_walk_tiles; no device).
+const void* fr_debug_walk_tiles(const uint32_t* run_pos, const uint32_t* run_q0, const uint32_t* run_q1, size_t nruns, const uint32_t* qstart,
+                                const uint32_t* qlen, size_t nq, size_t np) {
+    return json_call([&]() {
+        if (nruns > 0 && (!run_pos || !run_q0 || !run_q1)) fr::fail_str("fr_debug_walk_tiles: null run table");
+        if (nq > 0 && (!qstart || !qlen)) fr::fail_str("fr_debug_walk_tiles: null query table");
+        for (size_t q = 0; q < nq; q++)
+            if ((size_t)qstart[q] + qlen[q] > np) fr::fail_str("fr_debug_walk_tiles: a query lies beyond np");
+        for (size_t r = 0; r < nruns; r++)
+            if (run_q0[r] > run_q1[r] || run_q1[r] > nq) fr::fail_str("fr_debug_walk_tiles: a run names queries that do not exist");
+        const frdev::WalkTileLayout wl = frdev::build_walk_tiles(std::vector<uint32_t>(run_pos, run_pos + nruns), std::vector<uint32_t>(run_q0, run_q0 + nruns),
+                                                                std::vector<uint32_t>(run_q1, run_q1 + nruns), std::vector<uint32_t>(qstart, qstart + nq),
+                                                                std::vector<uint32_t>(qlen, qlen + nq), np);
+        Value o = Value::object();
+        auto list = [](const auto& v) {
+            Value a = Value::array();
+            for (auto x : v) a.push(Value::uint((uint64_t)x));
+            return a;
+        };
+        o.set("walk_tile", Value::uint(frdev::WALK_TILE));
+        o.set("wt_start", list(wl.wt_start));
+        o.set("run_wt0", list(wl.run_wt0));
+        o.set("seg", list(wl.seg));
+        o.set("wofs", list(wl.wofs));
+        return frjson::dump(o);
+    });
+}
+
 // The same call sequence on ONE device (a one-rank communicator): librccl.so opens, its symbols bind, ncclCommInitAll /
 // grouped ncclAllGather / ncclCommDestroy run and the data comes back.  What a one-GPU box can check of the exchange.
 const void* fr_debug_rccl_selftest(int device) {

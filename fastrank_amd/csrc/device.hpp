@@ -10,6 +10,7 @@
 //   * per-document gain (f32), 2^gain-1 (f64, host libm like the reference), relevance flag;
 //   * per-query offsets, a longest-first query schedule, log2(i+2) discount table.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -39,6 +40,72 @@ inline const char* pricing_env(const char* name) {
 }
 
 enum Measure : int { M_NDCG = 0, M_AP = 1, M_RR = 2 };
+
+// Walk tiles of the resident NDCG@k verify kernel (kernels_order.inc).  Every run's positions are cut, greedily and in query
+// order, into stretches of at most WALK_TILE positions such that a query of up to WALK_TILE documents is never cut; a longer
+// one is cut every WALK_TILE documents from its start and what is left of it shares a tile with the queries behind it.
+//   wt_start[i] = first position of tile i, ascending; one more entry = np (behind a run's last tile comes padding)
+//   run_wt0[r]  = the tile run r starts in (tiles never span runs)
+//   seg[p]      = first slot | (one past the last slot) << 8 of position p's (query, tile) segment, relative to the tile's
+//                 start; 0 for positions that hold no document
+//   wofs[p]     = p's offset inside its tile
+constexpr uint32_t WALK_TILE = 128;
+struct WalkTileLayout {
+    std::vector<uint32_t> wt_start, run_wt0;
+    std::vector<uint16_t> seg;
+    std::vector<uint8_t> wofs;
+};
+inline WalkTileLayout build_walk_tiles(const std::vector<uint32_t>& run_pos, const std::vector<uint32_t>& run_q0, const std::vector<uint32_t>& run_q1,
+                                       const std::vector<uint32_t>& qstart, const std::vector<uint32_t>& qlen, size_t np) {
+    constexpr uint32_t WT = WALK_TILE;
+    WalkTileLayout out;
+    std::vector<uint32_t>& wts = out.wt_start;
+    const size_t nruns = run_pos.size(), nq = qlen.size();
+    out.run_wt0.assign(nruns, 0);
+    for (size_t r = 0; r < nruns; r++) {
+        out.run_wt0[r] = (uint32_t)wts.size();
+        uint32_t start = run_pos[r], len = 0;
+        auto close = [&]() {
+            if (len == 0) return;
+            wts.push_back(start);
+            start += len;
+            len = 0;
+        };
+        for (uint32_t q = run_q0[r]; q < run_q1[r]; q++) {
+            uint32_t n = qlen[q];
+            if (n > WT) {
+                close();
+                for (; n > WT; n -= WT) {
+                    len = WT;
+                    close();
+                }
+                len = n;
+            } else {
+                if (len + n > WT) close();
+                len += n;
+            }
+        }
+        close();
+    }
+    const size_t nwt = wts.size();
+    wts.push_back((uint32_t)np);
+    out.seg.assign(np, 0);
+    out.wofs.assign(np, 0);
+    size_t t = 0;
+    for (size_t q = 0; q < nq; q++) {
+        const size_t b = qstart[q], e = b + qlen[q];
+        while (t + 1 < nwt && wts[t + 1] <= b) t++;
+        for (size_t u = t; u < nwt && wts[u] < e; u++) {
+            const size_t t0 = wts[u], t1 = std::min<size_t>((size_t)wts[u + 1], t0 + WT);
+            const size_t lo = std::max(b, t0) - t0, hi = std::min(e, t1) - t0;
+            for (size_t p = t0 + lo; p < t0 + hi; p++) {
+                out.seg[p] = (uint16_t)(lo | (hi << 8));
+                out.wofs[p] = (uint8_t)(p - t0);
+            }
+        }
+    }
+    return out;
+}
 
 // Error bound E >= |R - sum_j x_j v_j| of a trainer's resident sums, u = 2^-53, T from column
 // maxima.  One place for the constants: the trainer (host.hpp), compute_eps2 (device_dataset.inc) and the CPU test

@@ -290,6 +290,13 @@ def rccl_allgather_restarts(devices: List[int], parts: List[List[Dict]]) -> Tupl
     return rep, unpack_restart_records(out, dim)
 
 
+def walk_tiles(run_pos, run_q0, run_q1, qstart, qlen, np_positions: int) -> Dict:
+    """The walk tiles the device form of a dataset gets for this layout of runs and queries (no device needed)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (run_pos, run_q0, run_q1, qstart, qlen)]
+    return _json_reply(_load().fr_debug_walk_tiles(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, len(arrs[0]),
+                                                   arrs[3].ctypes.data, arrs[4].ctypes.data, len(arrs[3]), int(np_positions)))
+
+
 def rccl_selftest(device: int = 0) -> Dict:
     """A one-rank RCCL communicator on `device` through the library's exchange code (dlopen, ncclCommInitAll, grouped
     ncclAllGather, compare, destroy): the report of fr_rccl_allgather."""

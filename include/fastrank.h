@@ -251,6 +251,10 @@ const void *fr_unpack_restart_records(const double *records, size_t n_records, s
  * error envelope, not a fallback.  train_model's multi-device path runs it on the restarts' records itself
  * (fr_last_train_stats: "rccl"). */
 const void *fr_rccl_allgather(const int *devices, size_t n, const double *blocks, size_t block_len, double *out);
+/* The walk tiles of the resident NDCG@k verify kernel (csrc/device.hpp: build_walk_tiles) for a layout of runs and queries,
+ * computed on the host alone: JSON {"walk_tile":128,"wt_start":[...],"run_wt0":[...],"seg":[...],"wofs":[...]}. */
+const void *fr_debug_walk_tiles(const uint32_t *run_pos, const uint32_t *run_q0, const uint32_t *run_q1, size_t nruns,
+                                const uint32_t *qstart, const uint32_t *qlen, size_t nq, size_t np);
 /* The same call sequence with a one-rank communicator on `device` (what a one-GPU box can run of it): same JSON. */
 const void *fr_debug_rccl_selftest(int device);
 /* Frees the device-to-device copies train_model made of this dataset on other devices / in other contexts (they are kept

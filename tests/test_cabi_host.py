@@ -50,6 +50,64 @@ def test_pricing_switches_are_not_in_the_shipped_library():
     assert n <= 20, n
 
 
+def test_walk_tiles_cut_runs_at_query_boundaries():
+    """Round 6's layout for the resident NDCG@k verify kernel (csrc/device.hpp: build_walk_tiles; kernels_order.inc says why): a
+    run's positions are cut into tiles of at most 128 positions; a query of up to 128 documents lies inside ONE tile; a longer
+    one is cut every 128 documents from its start; tiles never span runs; every document's segment is the intersection of its
+    query and its tile, relative to the tile's start.  Host arithmetic only."""
+    rng = np.random.default_rng(17)
+    for trial in range(30):
+        nq = int(rng.integers(1, 60))
+        qlen = np.clip(rng.lognormal(np.log(60), 1.0, nq), 1, 700).astype(np.uint32)
+        if trial % 5 == 0:
+            qlen[rng.integers(0, nq)] = 128
+            qlen[rng.integers(0, nq)] = 129
+            qlen[rng.integers(0, nq)] = 256
+            qlen[rng.integers(0, nq)] = 1
+        # runs like DeviceDataset::create's: consecutive queries up to ~768 documents, every run starting on a multiple of 64
+        qstart, run_pos, run_q0, run_q1, pos, cur, q0 = [], [], [], [], 0, 0, 0
+        for q in range(nq):
+            if cur > 0 and cur + qlen[q] > 768:
+                run_pos.append(pos - cur), run_q0.append(q0), run_q1.append(q)
+                pos, cur, q0 = (pos + 63) // 64 * 64, 0, q
+            qstart.append(pos)
+            pos += int(qlen[q])
+            cur += int(qlen[q])
+        run_pos.append(pos - cur), run_q0.append(q0), run_q1.append(nq)
+        npos = (pos + 63) // 64 * 64
+        w = native.walk_tiles(run_pos, run_q0, run_q1, qstart, qlen, npos)
+        T, wt, seg, wofs = w["walk_tile"], w["wt_start"], w["seg"], w["wofs"]
+        assert T == 128 and wt[-1] == npos and wt[:-1] == sorted(set(wt[:-1])) and len(seg) == npos == len(wofs)
+        run_end = [qstart[b - 1] + int(qlen[b - 1]) for b in run_q1]
+        tile_len = []
+        for i in range(len(wt) - 1):
+            r = max(k for k in range(len(run_pos)) if run_pos[k] <= wt[i])          # the run the tile starts in
+            tile_len.append(min(wt[i + 1], run_end[r]) - wt[i])
+            assert 0 < tile_len[-1] <= T and wt[i] + tile_len[-1] <= run_end[r]     # inside its run, at most 128 positions
+        assert [wt[i] for i in w["run_wt0"]] == run_pos                             # a run starts a tile
+        covered = np.zeros(npos, dtype=bool)
+        for i, n in enumerate(tile_len):
+            assert not covered[wt[i]:wt[i] + n].any()
+            covered[wt[i]:wt[i] + n] = True
+        docs = np.zeros(npos, dtype=bool)
+        for q in range(nq):
+            b, e = qstart[q], qstart[q] + int(qlen[q])
+            docs[b:e] = True
+            tiles = [i for i in range(len(tile_len)) if wt[i] < e and wt[i] + tile_len[i] > b]
+            if qlen[q] <= T:
+                assert len(tiles) == 1, (trial, q, int(qlen[q]))                    # never cut
+            else:
+                assert [wt[i] for i in tiles] == [b + k * T for k in range(len(tiles))] and len(tiles) == -(-int(qlen[q]) // T)
+            for i in tiles:
+                lo, hi = max(b, wt[i]) - wt[i], min(e, wt[i] + tile_len[i]) - wt[i]
+                for pp in range(wt[i] + lo, wt[i] + hi):
+                    assert seg[pp] == (lo | (hi << 8)) and wofs[pp] == pp - wt[i]
+        assert np.array_equal(covered, docs)                                        # the tiles hold exactly the documents
+        assert all(seg[pp] == 0 for pp in np.nonzero(~docs)[0])
+    with pytest.raises(Exception, match="beyond np"):
+        native.walk_tiles([0], [0], [1], [0], [200], 128)
+
+
 def test_exchange_records_round_trip_bit_for_bit():
     """The records of the job's one all-gather (include/fastrank.h: fr_pack_restart_records): fixed-size blocks
     of (valid, restart id, score, weights), padded with invalid records -- what train_model's multi-device path and
