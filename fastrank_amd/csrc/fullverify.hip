@@ -14,26 +14,30 @@ namespace frdev {
 #include "kernels_sortnet.inc"
 #include "kernels_fullverify.inc"
 
-template <int NL, int PL, int MODE, bool TABLDS>
+template <int NL, int PL, int MODE, bool TABLDS, bool DUP = false>
 static bool fv_launch_one(const FVArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     // (more than the default 64 KB of dynamic LDS has to be asked for; per call: the attribute lives with the device's
     // copy of the function, and several devices may be in use)
     if (lds > (size_t(48) << 10) &&
-        hipFuncSetAttribute((const void*)fullrank_verify_kernel<NL, PL, MODE, TABLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void*)fullrank_verify_kernel<NL, PL, MODE, TABLDS, DUP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    fullrank_verify_kernel<NL, PL, MODE, TABLDS><<<grid, dim3(64 * FV_BLOCK_WAVES), lds, st>>>(a);
+    fullrank_verify_kernel<NL, PL, MODE, TABLDS, DUP><<<grid, dim3(64 * FV_BLOCK_WAVES), lds, st>>>(a);
     return true;
 }
 
+// (DUP: the duplicate-group rule, for depth-less NDCG and AP -- a depth that cuts the list keeps the plain rule, where a pair of
+// duplicates with different classes goes to the exact kernels)
 template <int NL, int PL>
 static bool fv_launch_class(int mode, bool tablds, const FVArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    if (mode == FV_AP) return fv_launch_one<NL, PL, FV_AP, false>(a, grid, lds, st);
+    const bool dup = a.dup != 0u;
+    if (mode == FV_AP) return dup ? fv_launch_one<NL, PL, FV_AP, false, true>(a, grid, lds, st) : fv_launch_one<NL, PL, FV_AP, false>(a, grid, lds, st);
     if (mode == FV_NDCG_CUT) return !tablds && fv_launch_one<NL, PL, FV_NDCG_CUT, false>(a, grid, lds, st);
     if (tablds) {
-        if constexpr (NL * PL <= 1024) return fv_launch_one<NL, PL, FV_NDCG, true>(a, grid, lds, st);
+        if constexpr (NL * PL <= 1024)
+            return dup ? fv_launch_one<NL, PL, FV_NDCG, true, true>(a, grid, lds, st) : fv_launch_one<NL, PL, FV_NDCG, true>(a, grid, lds, st);
         else return false;
     }
-    return fv_launch_one<NL, PL, FV_NDCG, false>(a, grid, lds, st);
+    return dup ? fv_launch_one<NL, PL, FV_NDCG, false, true>(a, grid, lds, st) : fv_launch_one<NL, PL, FV_NDCG, false>(a, grid, lds, st);
 }
 
 template <int CI>

@@ -34,6 +34,12 @@ struct FVArgs {
     uint64_t relmask;         // bit c set: gain class c is relevant (gain > 0)
     uint32_t G, ldm, dq, d, np, tablen, cls_mask;
     uint32_t padcls;          // class id of the padding keys (= number of gain classes; its termtab row is all zero)
+    // Duplicate groups (the DUP instantiations; dup != 0 when some query holds bit-identical rows with different gain classes):
+    // a key's low bits then hold class | group id << cls_bits (cls_mask covers both, cls_only_mask the class), inverted in a
+    // negative key -- see kernels_verify.inc, VERIFY_BITS_SRC -- and a pair of ONE group stands in the reference's tie-break
+    // order as sorted.  gkey[p] = class | group << key_cls_bits as the NDCG@k kernel keeps it (class ids without the padding class)
+    const uint16_t* gkey;
+    uint32_t dup, key_cls_bits, cls_bits, cls_only_mask;
     uint32_t nqc;             // queries in qlist
     uint32_t qb;              // queries a block sorts together (their candidates fill the lanes of its waves)
     uint32_t nrec;            // query records a block keeps in LDS: qb * (most batches any block walks)

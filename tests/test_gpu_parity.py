@@ -1445,6 +1445,48 @@ def test_fullrank_training_by_sort_and_verify(small, measure, ties):
     assert st["useful_evals"] == int(exp_e.sum())
 
 
+@pytest.mark.parametrize("measure", ["ndcg", "map"])
+def test_fullrank_verify_decides_mixed_label_duplicates(measure, monkeypatch):
+    """Round 6: bit-identical rows with DIFFERENT labels inside a query (their exact scores tie under every weight vector, the
+    reference orders them by gain ascending, src/evaluators.rs:34-49).  The sort-and-verify kernel's DUP instantiations carry
+    the duplicate-group id in the keys and accept a cluster whose pairs all belong to one group; without the rule
+    (FR_NO_DUP_GROUPS=1 when the dataset is made) every such pair goes to the exact kernels.  Same trajectory either way, the
+    oracle's; far fewer pairs redone with the rule.  Queries of 30-400 documents: single- and multi-lane size classes."""
+    rng = np.random.default_rng(41)
+    lens = rng.integers(30, 400, 24)
+    qid = np.repeat(np.arange(1, len(lens) + 1, dtype=np.int64), lens)
+    n = len(qid)
+    X = rng.normal(0, 1, (n, 12)).astype(np.float32)
+    y = rng.choice([0.0, 0.0, 1.0, 2.0, 3.0], n)
+    start = 0
+    for L in lens:  # a fifth of every query's documents are copies of others of the query, with labels of their own
+        k = int(L) // 5
+        src, dst = start + rng.integers(0, L, k), start + rng.integers(0, L, k)
+        X[dst] = X[src]
+        start += int(L)
+    c = o.Dataset(X, y, qid)
+    req = fr.TrainRequest.coordinate_ascent()
+    req.measure = measure
+    p = req.params
+    p.seed, p.quiet, p.num_restarts, p.num_max_iterations = 23, True, 3, 4
+    exp_s, exp_w, exp_e, err = c.ca_learn(measure, p.to_dict(), threads=2)
+    assert err == 0
+    redone = {}
+    for rule in (True, False):
+        if not rule:
+            monkeypatch.setenv("FR_NO_DUP_GROUPS", "1")
+        g = fr.CDataset.from_numpy(X, y, qid)
+        shard = native.train_model_shard(g, req, 0, 3)
+        st = shard["stats"]
+        assert st["path"] == "fused_fullrank"
+        for r in shard["restarts"]:
+            assert r["score"] == exp_s[r["restart_id"]] and r["weights"] == exp_w[r["restart_id"]].tolist(), rule
+        assert st["useful_evals"] == int(exp_e.sum())
+        redone[rule] = (st["verify_redone"], st["verify_pairs"])
+    if _verify_path_on() and not os.environ.get("FR_FV_OFF"):
+        assert redone[True][1] > 0 and redone[True][0] * 4 < redone[False][0], redone
+
+
 @pytest.mark.parametrize("measure", ["ndcg", "map", "ndcg@100"])
 def test_fullrank_verify_every_size_class(measure):
     """Queries of 1 .. 2048 documents cover every instantiation of the sort kernel (16/32/64 keys in one lane; 2, 4,

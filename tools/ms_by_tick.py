@@ -18,6 +18,8 @@ for t in range(ticks):
     t0 = time.perf_counter(); run.step(1); native.synchronize(); times.append((time.perf_counter() - t0) * 1e3)
     st = run.state()["stats"]; dp = st["verify_pairs"] - prev["verify_pairs"]
     redo.append((st["verify_redone"] - prev["verify_redone"]) / dp if dp else float("nan")); prev = st
+native.profile_reset(); native.profile_enable(True); run.step(4); native.synchronize(); native.profile_enable(False)
+print(measure, kind, "kernels, ms per tick over 4 more ticks:", {k: round(v["total_ms"] / 4, 2) for k, v in native.profile_stats().items()})
 print(measure, kind, "path", run.state()["stats"]["path"], "ms per tick:", " ".join("%.1f" % x for x in times))
 print(measure, kind, "pairs redone:", " ".join("%.4f" % x for x in redo))
 run.close()
