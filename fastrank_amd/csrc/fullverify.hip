@@ -25,13 +25,13 @@ static bool fv_launch_one(const FVArgs& a, dim3 grid, size_t lds, hipStream_t st
     return true;
 }
 
-// (DUP: the duplicate-group rule, for depth-less NDCG and AP -- a depth that cuts the list keeps the plain rule, where a pair of
-// duplicates with different classes goes to the exact kernels)
+// (DUP: the duplicate-group rule, chosen by the host when some query holds bit-identical rows with different gain classes)
 template <int NL, int PL>
 static bool fv_launch_class(int mode, bool tablds, const FVArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     const bool dup = a.dup != 0u;
     if (mode == FV_AP) return dup ? fv_launch_one<NL, PL, FV_AP, false, true>(a, grid, lds, st) : fv_launch_one<NL, PL, FV_AP, false>(a, grid, lds, st);
-    if (mode == FV_NDCG_CUT) return !tablds && fv_launch_one<NL, PL, FV_NDCG_CUT, false>(a, grid, lds, st);
+    if (mode == FV_NDCG_CUT)
+        return !tablds && (dup ? fv_launch_one<NL, PL, FV_NDCG_CUT, false, true>(a, grid, lds, st) : fv_launch_one<NL, PL, FV_NDCG_CUT, false>(a, grid, lds, st));
     if (tablds) {
         if constexpr (NL * PL <= 1024)
             return dup ? fv_launch_one<NL, PL, FV_NDCG, true, true>(a, grid, lds, st) : fv_launch_one<NL, PL, FV_NDCG, true>(a, grid, lds, st);

@@ -1445,13 +1445,14 @@ def test_fullrank_training_by_sort_and_verify(small, measure, ties):
     assert st["useful_evals"] == int(exp_e.sum())
 
 
-@pytest.mark.parametrize("measure", ["ndcg", "map"])
+@pytest.mark.parametrize("measure", ["ndcg", "map", "ndcg@25", "ndcg@150"])
 def test_fullrank_verify_decides_mixed_label_duplicates(measure, monkeypatch):
     """Round 6: bit-identical rows with DIFFERENT labels inside a query (their exact scores tie under every weight vector, the
     reference orders them by gain ascending, src/evaluators.rs:34-49).  The sort-and-verify kernel's DUP instantiations carry
     the duplicate-group id in the keys and accept a cluster whose pairs all belong to one group; without the rule
     (FR_NO_DUP_GROUPS=1 when the dataset is made) every such pair goes to the exact kernels.  Same trajectory either way, the
-    oracle's; far fewer pairs redone with the rule.  Queries of 30-400 documents: single- and multi-lane size classes."""
+    oracle's; far fewer pairs redone with the rule.  Queries of 30-400 documents: single- and multi-lane size classes; the
+    depths 25 and 150 cut the lists in their first lane and in later ones (only clusters that reach into the cut matter)."""
     rng = np.random.default_rng(41)
     lens = rng.integers(30, 400, 24)
     qid = np.repeat(np.arange(1, len(lens) + 1, dtype=np.int64), lens)
