@@ -468,6 +468,19 @@ def side_kind(args, comm, fr, native, req, kind, begin, end, headline_value):
     X, y, qid = gen_mslr_shaped(seed, n, d, q, kind)
     gen_s = time.perf_counter() - t0
     ds = fr.CDataset.from_numpy(X, y, qid)
+    # (as for the headline, main(): a throwaway first job uploads the data and pre-heats the device, which has just idled through
+    # `generate_s` of host work; the measured job starts from its own fresh state)
+    preheat = 0 if os.environ.get("FR_BENCH_NO_PREHEAT") else 100
+    seed = req.params.seed
+    req.params.seed = 7
+    pre = native.CoordinateAscentRun(ds, req, begin, end)
+    try:
+        if preheat and end > begin:
+            pre.step(preheat)
+            comm.sync_device()
+    finally:
+        pre.close()
+        req.params.seed = seed
     run = native.CoordinateAscentRun(ds, req, begin, end)
     try:
         run.step(args.warmup)
@@ -498,7 +511,7 @@ def side_kind(args, comm, fr, native, req, kind, begin, end, headline_value):
             "chain_runs_per_visit": ((s1["chain_runs"] - s0["chain_runs"]) / (s1["chain_visits"] - s0["chain_visits"])) if s1.get("chain_visits", 0) > s0.get("chain_visits", 0) else None,
             "exact_kernel_ms_per_step": prof.get("linesearch_ndcg_kernel", {"total_ms": 0.0})["total_ms"] / psteps,
             "kernels_ms_per_step": {k: v["total_ms"] / psteps for k, v in prof.items()},
-            "generate_s": gen_s}
+            "generate_s": gen_s, "preheat_ticks": preheat}
 
 
 def rccl_is_mandatory(backend, world, visible_gpus, pinned_device):
@@ -1207,6 +1220,11 @@ def rank_main(args, comm, fr, native, X, y, qid, gen_s, dev_ordinal, thread_devi
         }
         if world == 1 and headline and not args.no_side:
             p.seed = 42
+            # (the headline's dataset goes first -- free_dataset, as a caller done with it would: its tiles, order tables and
+            # line-search contexts with their streams otherwise stay beside the side line's)
+            dataset = None
+            import gc
+            gc.collect()
             try:
                 out["side"] = {"hardties": side_kind(args, comm, fr, native, req, "hardties", begin, end, out["value"])}
             except Exception as exc:  # (a side leg: its failure must not cost the bench line -- it is reported in it)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The short form of r06_final.sh after a change that leaves the headline kernel alone: suite + smoke, PMC of the headline (so that the
-# bench line written afterwards carries pmc.stale = false), the final bench line, the full-ranking measures by tick on the data kinds.
+# bench line written afterwards carries pmc.stale = false), the final bench line, the five data kinds on one box, the full-ranking
+# measures by tick on the data kinds.
 cd "$GRAFT_REPO_ROOT"; TAG=${1:-r06}
 bash tools/ab/gpu_suite.sh
 cp gpurun_out/suite/gputest.log gpurun_out/${TAG}_gputest.log
@@ -10,6 +11,7 @@ cp profiles/hbm_traffic.json gpurun_out/hbm_traffic.json
 mkdir -p gpurun_out/r04b
 python bench.py --steps 20 --warmup 5 > gpurun_out/r04b/bench_final.json 2> /dev/null; python -c "
 import json; d=json.loads(open('gpurun_out/r04b/bench_final.json').read().strip().splitlines()[-1]); print('final', d['value'], d['value_runs_min_median_max'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['pmc']['stale'], d['limiter']['frac'], d['roofline']['hbm_frac_measured'], d['cpu_baseline']['min_median_max'], d.get('side'))"
+tools/ab/r05_kinds.sh ${TAG}_kinds 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_kinds.txt; cat gpurun_out/${TAG}_kinds.txt
 {
   echo "# tools/ms_by_tick.py (30K shape, 32 restarts, single-stepped ticks from the start of a job): the full-ranking measures by data kind"
   for mk in "ndcg mslr" "map mslr" "ndcg@30 mslr" "ndcg ties" "ndcg tiesmix" "map tiesmix" "ndcg@30 tiesmix" "ndcg hardties" "map hardties"; do
