@@ -12,16 +12,7 @@ mkdir -p gpurun_out/r04b
 python bench.py --steps 20 --warmup 5 > gpurun_out/r04b/bench_final.json 2> /dev/null; python -c "
 import json; d=json.loads(open('gpurun_out/r04b/bench_final.json').read().strip().splitlines()[-1]); print('final', d['value'], d['value_runs_min_median_max'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['pmc']['stale'], d['limiter']['frac'], d['roofline']['hbm_frac_measured'], d['cpu_baseline']['min_median_max'], d.get('side'))"
 tools/ab/r05_kinds.sh ${TAG}_kinds 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_kinds.txt; cat gpurun_out/${TAG}_kinds.txt
-{
-  echo "# tools/ms_by_tick.py (30K shape, 32 restarts, single-stepped ticks from the start of a job): the full-ranking measures by data kind"
-  for mk in "ndcg mslr" "map mslr" "ndcg@30 mslr" "ndcg ties" "ndcg tiesmix" "map tiesmix" "ndcg@30 tiesmix" "ndcg hardties" "map hardties"; do
-    python tools/ms_by_tick.py $mk 10 2>/dev/null | grep -v kernels | cut -c1-220
-  done
-  echo "# the same with FR_NO_DUP_GROUPS=1 (no duplicate-group ids in the keys: the rule as it was before this round's DUP instantiations)"
-  for mk in "ndcg tiesmix" "ndcg@30 tiesmix"; do
-    FR_NO_DUP_GROUPS=1 python tools/ms_by_tick.py $mk 10 2>/dev/null | grep -v kernels | cut -c1-220
-  done
-} > gpurun_out/${TAG}_fullrank_by_tick.txt; cat gpurun_out/${TAG}_fullrank_by_tick.txt
+bash tools/ab/r06_fullrank_by_tick.sh $TAG
 rm -rf gpurun_out/pmc_bench/sq gpurun_out/pmc_bench/mix gpurun_out/pmc_bench/fetch gpurun_out/pmc_bench/write
 find gpurun_out -name "*.csv" -size +2M -delete
 du -sh gpurun_out

@@ -15,6 +15,7 @@ tools/ab/r05_kinds.sh ${TAG}_kinds 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}
 bash tools/ab/r04_bench.sh 2>&1 | tail -14
 python bench.py --steps 20 --warmup 5 > gpurun_out/r04b/bench_final.json 2> /dev/null; python -c "
 import json; d=json.loads(open('gpurun_out/r04b/bench_final.json').read().strip().splitlines()[-1]); print('final', d['value'], d['value_runs_min_median_max'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['pmc']['stale'], d['limiter']['frac'], d['roofline']['hbm_frac_measured'], d['cpu_baseline']['min_median_max'])"
+bash tools/ab/r06_fullrank_by_tick.sh $TAG > /dev/null
 # what travels back is capped at 64 MiB: keep the summaries, drop the raw rocprofv3 output they were made from
 rm -rf gpurun_out/pmc_bench/sq gpurun_out/pmc_bench/mix gpurun_out/pmc_bench/fetch gpurun_out/pmc_bench/write \
        gpurun_out/pmc_trees/sq1 gpurun_out/pmc_trees/sq2 gpurun_out/pmc_trees/fetch gpurun_out/pmc_trees/write \

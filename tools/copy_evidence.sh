@@ -18,3 +18,4 @@ cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json
 cp gpurun_out/pmc_bench/summary.json profiles/${TAG}_pmc_bench_summary.json
 cp gpurun_out/pmc_trees/summary.json profiles/${TAG}_pmc_trees_summary.json
 cp gpurun_out/${TAG}_pmc_verify/summary.txt profiles/${TAG}_pmc_verify_summary.txt
+cp gpurun_out/${TAG}_fullrank_by_tick.txt profiles/${TAG}_fullrank_by_tick.txt

@@ -11,7 +11,8 @@ mkdir -p "$OUT"
 # 1. the bench line (HIP-event roofline inside)
 python bench.py --steps 20 --warmup 3 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 # 2. rocprofv3 kernel trace + stats of the same command
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o p -- python bench.py --steps 20 --warmup 3 > "$OUT/kt.log" 2>&1
+# (without the pre-heating throwaway job and the hardties side line, so that the launches below sort into the legs by their order alone)
+FR_BENCH_NO_PREHEAT=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o p -- python bench.py --steps 20 --warmup 3 --no-side > "$OUT/kt.log" 2>&1
 cp "$OUT"/kt/*kernel_stats.csv "$OUT/${TAG}_kernel_stats.csv" 2>/dev/null || cp "$OUT"/kt/*/*kernel_stats.csv "$OUT/${TAG}_kernel_stats.csv"
 # the dominant kernel's launches by kind (the trainer keeps three launches in flight, bench.py appends isolated ones)
 python - "$OUT" > "$OUT/${TAG}_verify_launches.txt" <<'PY'
@@ -27,8 +28,8 @@ first_iso, last_iso = rows.index(iso[0]), rows.index(iso[-1])
 rest = rows[:first_iso]                 # warm-up, timed, then the instrumented pipelined steps (bench.py's legs in order)
 e2e = rows[last_iso + 1:]               # the train-to-convergence leg
 warm, timed, instr = rest[:9], rest[9:69], rest[69:]
-print("rocprofv3 --kernel-trace of `python bench.py --steps 20 --warmup 3`: linesearch_verify_kernel launches by kind")
-for name, sel in (("warm-up (3 ticks x 3 sets)", warm), ("timed (20 ticks x 3 sets, overlapping)", timed), ("instrumented pipelined steps after them", instr),
+print("rocprofv3 --kernel-trace of `FR_BENCH_NO_PREHEAT=1 python bench.py --steps 20 --warmup 3 --no-side`: linesearch_verify_kernel launches by kind")
+for name, sel in (("warm-up (3 ticks x 3 sets)", warm), ("timed (20 ticks x 3 sets, overlapping)", timed), ("repeats of the timed region, instrumented pipelined steps", instr),
                   ("isolated lock-step (32 groups)", iso), ("train-to-convergence leg (408 ticks x 3 sets, fewer groups as restarts converge)", e2e)):
     if sel:
         d = [dur(r) for r in sel]
